@@ -1,0 +1,121 @@
+// Host side of the network: state-dict intake, repacking into kernel layouts,
+// workspace management and the forward schedule.
+// Mirrors PolicyValueNet (azchess/model/resnet.py:285-582 ctor, 656-760 forward)
+// for the inference configuration the self-play path uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/m0_engine.h"
+#include "net_kernels.h"
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct PackedGemm {
+    _Float16* w = nullptr;   // [taps][Cin/KC][N][KC]
+    float* bias = nullptr;   // [N] or null
+    int taps = 1, Cin = 0, N = 0;
+};
+
+struct NormParams {
+    float* gamma = nullptr;
+    float* beta = nullptr;
+};
+
+struct ResBlockW {
+    PackedGemm conv1, conv2;
+    NormParams bn1, bn2;
+    float *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
+    int se_hidden = 0;
+};
+
+struct AttnW {
+    PackedGemm qkv, proj;
+    NormParams ln;
+    float* rel_bias = nullptr;
+};
+
+struct TowerLayer {
+    int kind;    // 0 = residual block, 1 = attention
+    int index;   // into res / att vectors
+    bool skip;   // inference attention stride (resnet.py:678-687)
+};
+
+struct SslHeadW {
+    std::string task;
+    PackedGemm c0, c1;
+    NormParams n;
+    int out_ch = 0;
+    int hidden = 0;
+};
+
+class Net {
+public:
+    explicit Net(const m0_net_cfg& cfg, int device);
+    ~Net();
+    static const char* check_supported(const m0_net_cfg& cfg);
+    int load(const char* name, const void* data, int dtype, const int64_t* shape, int ndim, std::string& err);
+    int finalize(std::string& err);
+    bool ready() const { return finalized_; }
+    // planes: device f32 [B][planes][64] (planes_dev) or device fp16 NHWC [B][64][32] (nhwc_dev)
+    // outputs (device): logits f32 [B][4672], value f32 [B]; ssl (optional) f32 concatenated
+    int forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float* logits_dev, float* value_dev,
+                float* ssl_dev, hipStream_t st, std::string& err);
+    int ensure_workspace(int B, std::string& err);
+    int ssl_channels_total() const;
+    const m0_net_cfg& cfg() const { return cfg_; }
+    size_t param_count() const { return nparams_; }
+    double flops_per_position(bool with_ssl) const;
+    _Float16* input_nhwc() { return X0_; }   // engine-side encoders write here directly
+
+private:
+    m0_net_cfg cfg_;
+    int device_;
+    bool finalized_ = false;
+    size_t nparams_ = 0;
+    std::map<std::string, HostTensor> sd_;
+    std::vector<void*> dev_allocs_;
+    std::vector<void*> ws_allocs_;
+
+    int C_ = 0, Cs_ = 0 /*ssl hidden padded*/;
+    PackedGemm stem_;
+    NormParams stem_n_;
+    float* posenc_ = nullptr;
+    PackedGemm pst_, inter_;
+    NormParams pst_n_, inter_n_;
+    std::vector<ResBlockW> res_;
+    std::vector<AttnW> att_;
+    std::vector<TowerLayer> tower_;
+    PackedGemm ph_conv_, pfc1_, pfc2_;
+    NormParams ph_n_;
+    float logit_scale_ = 1.f;
+    PackedGemm vh0_, vh3_, vfc1_, vfc2_, vgate_, vfc3_;
+    NormParams vh1_n_, vh4_n_;
+    std::vector<SslHeadW> ssl_;
+    uint64_t* mask_dev_ = nullptr;
+
+    // workspace
+    int wsB_ = 0, wsM_ = 0;
+    _Float16 *X0_ = nullptr, *XA_ = nullptr, *XB_ = nullptr, *T1_ = nullptr, *T2_ = nullptr, *QKV_ = nullptr,
+             *O_ = nullptr;
+    float *SX_ = nullptr, *S1_ = nullptr, *S2_ = nullptr;
+    _Float16 *PH_ = nullptr, *PH2_ = nullptr, *VH_ = nullptr, *VH2_ = nullptr, *F1_ = nullptr, *F2_ = nullptr,
+             *F3_ = nullptr, *F4_ = nullptr, *SH_ = nullptr, *SH2_ = nullptr, *SO_ = nullptr;
+    float* LOG_ = nullptr;
+    float* VAL_ = nullptr;
+
+    const HostTensor* get(const std::string& k, std::string& err);
+    int pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
+                  int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err);
+    int upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err);
+    float* upload_f32(const std::vector<float>& v);
+    void* dalloc(size_t bytes, bool ws);
+    hipError_t run_gemm(const PackedGemm& g, const _Float16* in, void* out, int Mrows, int Mvalid,
+                        const float* in_stats, const NormParams* in_norm, int pro_act, int epi_act,
+                        const _Float16* mul, float* out_stats, bool out_f32, float out_scale, hipStream_t st);
+};

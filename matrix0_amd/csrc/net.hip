@@ -1,0 +1,475 @@
+// Host side of the network forward (see net.h).
+#include "net.h"
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+#define HIPCHK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                         \
+            return M0_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+static const char* kSslNames[5] = {"piece", "threat", "pin", "fork", "control"};
+static const int kSslOut[5] = {13, 1, 1, 1, 3};
+
+const char* Net::check_supported(const m0_net_cfg& c) {
+    if (!c.norm_group) return "HIP path supports norm='group' only (BatchNorm configs are not built)";
+    if (!c.preact) return "HIP path supports preact=true only";
+    if (c.channels % 32 != 0 || c.channels < 32 || c.channels > 512) return "channels must be a multiple of 32 in [32,512]";
+    if (c.planes < 1 || c.planes > 32) return "planes must be in [1,32]";
+    if (c.attention && (c.attention_heads <= 0 || c.channels % c.attention_heads != 0 ||
+                        c.channels / c.attention_heads != 16))
+        return "attention head_dim (channels/attention_heads) must be 16";
+    if (c.activation != M0_ACT_SILU && c.activation != M0_ACT_RELU) return "activation must be silu or relu";
+    if (c.blocks < 1) return "blocks must be >= 1";
+    if (c.policy_factor_rank < 0) return "policy_factor_rank must be >= 0";
+    if (c.self_supervised && c.ssl_tasks && (c.channels / 2) % 16 != 0) return "ssl heads need channels/2 % 16 == 0";
+    return nullptr;
+}
+
+Net::Net(const m0_net_cfg& cfg, int device) : cfg_(cfg), device_(device) {
+    C_ = cfg.channels;
+    Cs_ = ceil_to(std::max(16, C_ / 2), 32);
+    int k = cfg.attention_every_k;
+    int stride = std::max(1, cfg.infer_attention_stride);
+    int att_seen = 0;
+    for (int i = 0; i < cfg.blocks; ++i) {
+        tower_.push_back({0, (int)res_.size(), false});
+        res_.emplace_back();
+        if (cfg.attention && k > 0 && (i % k) == (k - 1)) {
+            ++att_seen;
+            bool skip = stride > 1 && (att_seen % stride) != 0;
+            tower_.push_back({1, (int)att_.size(), skip});
+            att_.emplace_back();
+        }
+    }
+}
+
+Net::~Net() {
+    for (void* p : dev_allocs_) (void)hipFree(p);
+    for (void* p : ws_allocs_) (void)hipFree(p);
+}
+
+void* Net::dalloc(size_t bytes, bool ws) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, bytes);
+    (ws ? ws_allocs_ : dev_allocs_).push_back(p);
+    return p;
+}
+
+float* Net::upload_f32(const std::vector<float>& v) {
+    float* d = (float*)dalloc(v.size() * 4, false);
+    if (d && !v.empty()) (void)hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+    return d;
+}
+
+int Net::load(const char* name, const void* data, int dtype, const int64_t* shape, int ndim, std::string& err) {
+    if (finalized_) { err = "weights already finalized"; return M0_ERR_STATE; }
+    if (!name || (!data && ndim >= 0)) { err = "null argument"; return M0_ERR_INVALID; }
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.resize(n);
+    if (dtype == 0) memcpy(t.data.data(), data, n * 4);
+    else if (dtype == 1) {
+        const _Float16* h = (const _Float16*)data;
+        for (size_t i = 0; i < n; ++i) t.data[i] = (float)h[i];
+    } else { err = "dtype must be 0 (f32) or 1 (f16)"; return M0_ERR_INVALID; }
+    std::string key(name);
+    // resnet.py:1405-1416: legacy rename policy_fc.* -> policy_fc1.* only matters for factorised heads
+    if (cfg_.policy_factor_rank > 0 && key.rfind("policy_fc.", 0) == 0) key = "policy_fc1." + key.substr(10);
+    sd_[key] = std::move(t);
+    return M0_OK;
+}
+
+const HostTensor* Net::get(const std::string& k, std::string& err) {
+    auto it = sd_.find(k);
+    if (it == sd_.end()) { err = "missing state-dict key: " + k; return nullptr; }
+    return &it->second;
+}
+
+int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
+                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err) {
+    const HostTensor* w = get(wkey, err);
+    if (!w) return M0_ERR_INVALID;
+    size_t expect = (size_t)N_real * Cin_real * taps;
+    if (w->data.size() != expect) { err = "shape mismatch for " + wkey; return M0_ERR_INVALID; }
+    nparams_ += expect;
+    const int KC = conv_gemm_kc(Cin_pad, N_pad);
+    const int nchunk = Cin_pad / KC;
+    std::vector<_Float16> p((size_t)taps * Cin_pad * N_pad, (_Float16)0.f);
+    for (int n = 0; n < N_real; ++n)
+        for (int k = 0; k < Cin_real; ++k)
+            for (int t = 0; t < taps; ++t) {
+                float v = w->data[((size_t)n * Cin_real + k) * taps + t];
+                int kk = k;
+                if (k_perm_ch > 0) {           // reference flatten index c*64+sq -> ours sq*Cp+c
+                    int c = k / 64, sq = k % 64;
+                    kk = sq * k_perm_ch + c;
+                }
+                int chunk = kk / KC, kc = kk % KC;
+                p[(((size_t)t * nchunk + chunk) * N_pad + n) * KC + kc] = (_Float16)v;
+            }
+    g.w = (_Float16*)dalloc(p.size() * 2, false);
+    if (!g.w) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+    (void)hipMemcpy(g.w, p.data(), p.size() * 2, hipMemcpyHostToDevice);
+    g.taps = taps; g.Cin = Cin_pad; g.N = N_pad;
+    g.bias = nullptr;
+    if (!bkey.empty()) {
+        const HostTensor* b = get(bkey, err);
+        if (!b) return M0_ERR_INVALID;
+        if ((int)b->data.size() != N_real) { err = "shape mismatch for " + bkey; return M0_ERR_INVALID; }
+        nparams_ += N_real;
+        std::vector<float> bp(N_pad, 0.f);
+        std::copy(b->data.begin(), b->data.end(), bp.begin());
+        g.bias = upload_f32(bp);
+    }
+    return M0_OK;
+}
+
+int Net::upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err) {
+    const HostTensor* g = get(prefix + ".weight", err);
+    if (!g) return M0_ERR_INVALID;
+    const HostTensor* b = get(prefix + ".bias", err);
+    if (!b) return M0_ERR_INVALID;
+    if ((int)g->data.size() != C_real || (int)b->data.size() != C_real) { err = "shape mismatch for " + prefix; return M0_ERR_INVALID; }
+    nparams_ += 2 * (size_t)C_real;
+    std::vector<float> gp(C_pad, 0.f), bp(C_pad, 0.f);
+    std::copy(g->data.begin(), g->data.end(), gp.begin());
+    std::copy(b->data.begin(), b->data.end(), bp.begin());
+    n.gamma = upload_f32(gp);
+    n.beta = upload_f32(bp);
+    return M0_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != M0_OK) return rc_; } while (0)
+
+int Net::finalize(std::string& err) {
+    if (finalized_) return M0_OK;
+    if (hipSetDevice(device_) != hipSuccess) { err = "hipSetDevice failed"; return M0_ERR_HIP; }
+    const int C = C_;
+    nparams_ = 0;
+    TRY(pack_gemm(stem_, "stem.0.weight", "", 9, cfg_.planes, 32, C, C, 0, err));
+    TRY(upload_norm(stem_n_, "stem.1", C, C, err));
+    if (cfg_.chess_features) {
+        const HostTensor* pe = get("chess_features.position_encoding", err);
+        if (!pe) return M0_ERR_INVALID;
+        if ((int)pe->data.size() != C * 64) { err = "shape mismatch for position_encoding"; return M0_ERR_INVALID; }
+        nparams_ += pe->data.size();
+        std::vector<float> t((size_t)64 * C);
+        for (int c = 0; c < C; ++c)
+            for (int n = 0; n < 64; ++n) t[(size_t)n * C + c] = pe->data[(size_t)c * 64 + n];
+        posenc_ = upload_f32(t);
+        if (cfg_.piece_square_tables) {
+            TRY(pack_gemm(pst_, "chess_features.pst_conv.weight", "", 1, C, C, C, C, 0, err));
+            TRY(upload_norm(pst_n_, "chess_features.pst_norm", C, C, err));
+        }
+        TRY(pack_gemm(inter_, "chess_features.interaction_conv.weight", "", 9, C, C, C, C, 0, err));
+        TRY(upload_norm(inter_n_, "chess_features.interaction_norm", C, C, err));
+    }
+    int ti = 0;
+    for (auto& L : tower_) {
+        std::string p = "tower." + std::to_string(ti++);
+        if (L.kind == 0) {
+            ResBlockW& r = res_[L.index];
+            TRY(pack_gemm(r.conv1, p + ".conv1.weight", "", 9, C, C, C, C, 0, err));
+            TRY(pack_gemm(r.conv2, p + ".conv2.weight", "", 9, C, C, C, C, 0, err));
+            TRY(upload_norm(r.bn1, p + ".bn1", C, C, err));
+            TRY(upload_norm(r.bn2, p + ".bn2", C, C, err));
+            if (cfg_.se) {
+                int hd = std::max(8, (int)(C * cfg_.se_ratio));
+                r.se_hidden = hd;
+                const HostTensor* w1 = get(p + ".se_fc1.weight", err); if (!w1) return M0_ERR_INVALID;
+                const HostTensor* b1 = get(p + ".se_fc1.bias", err); if (!b1) return M0_ERR_INVALID;
+                const HostTensor* w2 = get(p + ".se_fc2.weight", err); if (!w2) return M0_ERR_INVALID;
+                const HostTensor* b2 = get(p + ".se_fc2.bias", err); if (!b2) return M0_ERR_INVALID;
+                if ((int)w1->data.size() != hd * C || (int)w2->data.size() != hd * C || (int)b1->data.size() != hd ||
+                    (int)b2->data.size() != C) { err = "shape mismatch for " + p + ".se_*"; return M0_ERR_INVALID; }
+                nparams_ += (size_t)2 * hd * C + hd + C;
+                std::vector<float> w1t((size_t)C * hd);       // [C][hd] from [hd][C]
+                for (int j = 0; j < hd; ++j)
+                    for (int c = 0; c < C; ++c) w1t[(size_t)c * hd + j] = w1->data[(size_t)j * C + c];
+                r.se_w1 = upload_f32(w1t);
+                r.se_b1 = upload_f32(b1->data);
+                r.se_w2 = upload_f32(w2->data);               // already [C][hd]
+                r.se_b2 = upload_f32(b2->data);
+            }
+        } else {
+            AttnW& a = att_[L.index];
+            if (L.skip) {   // never executed at inference; count parameters, keep nothing resident
+                for (const char* k : {".qkv.weight", ".proj.weight", ".norm.weight", ".norm.bias", ".rel_bias"}) {
+                    auto it = sd_.find(p + k);
+                    if (it != sd_.end()) nparams_ += it->second.data.size();
+                }
+                continue;
+            }
+            TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, C, 3 * C, 3 * C, 0, err));
+            TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, C, C, C, 0, err));
+            TRY(upload_norm(a.ln, p + ".norm", C, C, err));
+            if (cfg_.attention_relbias) {
+                const HostTensor* rb = get(p + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
+                if ((int)rb->data.size() != cfg_.attention_heads * 4096) { err = "shape mismatch for rel_bias"; return M0_ERR_INVALID; }
+                nparams_ += rb->data.size();
+                a.rel_bias = upload_f32(rb->data);
+            }
+        }
+    }
+    // attention visibility mask, resnet.py:104-130
+    {
+        std::vector<uint64_t> m(64, 0);
+        for (int i = 0; i < 64; ++i)
+            for (int j = 0; j < 64; ++j) {
+                int dr = i / 8 - j / 8, dc = i % 8 - j % 8;
+                int adr = abs(dr), adc = abs(dc);
+                bool vis = dr == 0 || dc == 0 || adr == adc || (adr == 2 && adc == 1) || (adr == 1 && adc == 2) ||
+                           (adr <= 1 && adc <= 1);
+                if (vis) m[i] |= (1ull << j);
+            }
+        mask_dev_ = (uint64_t*)dalloc(64 * 8, false);
+        (void)hipMemcpy(mask_dev_, m.data(), 64 * 8, hipMemcpyHostToDevice);
+    }
+    // policy head
+    TRY(pack_gemm(ph_conv_, "policy_head.0.weight", "", 1, C, C, 64, 64, 0, err));
+    TRY(upload_norm(ph_n_, "policy_head.1", 64, 64, err));
+    if (cfg_.policy_factor_rank > 0) {
+        int r = cfg_.policy_factor_rank, rp = ceil_to(r, 32);
+        TRY(pack_gemm(pfc1_, "policy_fc1.weight", "policy_fc1.bias", 1, 4096, 4096, r, rp, 64, err));
+        TRY(pack_gemm(pfc2_, "policy_fc2.weight", "policy_fc2.bias", 1, r, rp, M0_POLICY_SIZE, M0_POLICY_SIZE, 0, err));
+    } else {
+        TRY(pack_gemm(pfc1_, "policy_fc.weight", "policy_fc.bias", 1, 4096, 4096, M0_POLICY_SIZE, M0_POLICY_SIZE, 64, err));
+    }
+    {
+        const HostTensor* ls = get("_policy_logit_scale_raw", err); if (!ls) return M0_ERR_INVALID;
+        nparams_ += 1;
+        double raw = ls->data.empty() ? 0.0 : ls->data[0];
+        double sp = raw > 20.0 ? raw : log1p(exp(raw));
+        logit_scale_ = (float)std::min(5.0, sp + 1e-3);
+    }
+    // value head
+    TRY(pack_gemm(vh0_, "value_head.0.weight", "", 1, C, C, 128, 128, 0, err));
+    TRY(upload_norm(vh1_n_, "value_head.1", 128, 128, err));
+    TRY(pack_gemm(vh3_, "value_head.3.weight", "", 1, 128, 128, 128, 128, 0, err));
+    TRY(upload_norm(vh4_n_, "value_head.4", 128, 128, err));
+    {
+        int h1 = 2 * C, h1p = ceil_to(h1, 32), h2 = C, h2p = ceil_to(C, 32);
+        TRY(pack_gemm(vfc1_, "value_fc1.weight", "value_fc1.bias", 1, 8192, 8192, h1, h1p, 128, err));
+        TRY(pack_gemm(vfc2_, "value_fc2.weight", "value_fc2.bias", 1, h1, h1p, h2, h2p, 0, err));
+        TRY(pack_gemm(vgate_, "value_gate.0.weight", "value_gate.0.bias", 1, h2, h2p, h2, h2p, 0, err));
+        TRY(pack_gemm(vfc3_, "value_fc3.weight", "value_fc3.bias", 1, h2, h2p, 1, 32, 0, err));
+    }
+    // ssl heads
+    if (cfg_.self_supervised) {
+        for (int t = 0; t < 5; ++t) {
+            if (!(cfg_.ssl_tasks & (1 << t))) continue;
+            SslHeadW h;
+            h.task = kSslNames[t];
+            h.out_ch = kSslOut[t];
+            h.hidden = C / 2;
+            std::string p = std::string("ssl_heads.") + kSslNames[t];
+            TRY(pack_gemm(h.c0, p + ".0.weight", "", 1, C, C, C / 2, Cs_, 0, err));
+            TRY(upload_norm(h.n, p + ".1", C / 2, Cs_, err));
+            TRY(pack_gemm(h.c1, p + ".3.weight", "", 1, C / 2, Cs_, h.out_ch, 32, 0, err));
+            ssl_.push_back(h);
+        }
+    }
+    sd_.clear();
+    finalized_ = true;
+    return M0_OK;
+}
+
+int Net::ssl_channels_total() const {
+    int n = 0;
+    for (auto& h : ssl_) n += h.out_ch;
+    return n;
+}
+
+double Net::flops_per_position(bool with_ssl) const {
+    // MAC count of the executed graph (SURVEY App. A.4 convention: 2 FLOP per MAC)
+    const double C = C_;
+    double mac = 64.0 * cfg_.planes * 9 * C;                                   // stem
+    if (cfg_.chess_features) mac += 64.0 * C * C * (cfg_.piece_square_tables ? 1 : 0) + 64.0 * C * C * 9;
+    for (auto& L : tower_) {
+        if (L.kind == 0) {
+            mac += 2 * 64.0 * C * C * 9;
+            if (cfg_.se) mac += 2.0 * C * res_[L.index].se_hidden;
+        } else if (!L.skip) {
+            mac += 64.0 * C * 3 * C + 64.0 * C * C;                            // qkv + proj
+            double nb = (cfg_.attention_unmasked_mix > 0.f && cfg_.attention_unmasked_mix < 1.f) ? 2.0 : 1.0;
+            mac += 64.0 * 64.0 * C * (1.0 + nb);                               // QK^T + AV per branch
+        }
+    }
+    mac += 64.0 * C * 64;
+    if (cfg_.policy_factor_rank > 0) mac += 4096.0 * cfg_.policy_factor_rank + (double)cfg_.policy_factor_rank * M0_POLICY_SIZE;
+    else mac += 4096.0 * M0_POLICY_SIZE;
+    mac += 64.0 * C * 128 + 64.0 * 128 * 128 + 8192.0 * 2 * C + 2.0 * C * C + C * C + C;
+    if (with_ssl) for (auto& h : ssl_) mac += 64.0 * C * (C / 2) + 64.0 * (C / 2) * h.out_ch;
+    return 2.0 * mac;
+}
+
+int Net::ensure_workspace(int B, std::string& err) {
+    const int Bp = ceil_to(B, 4);
+    const int Mfc = ceil_to(B, 256);
+    if (Bp <= wsB_ && Mfc <= wsM_) return M0_OK;
+    if (hipSetDevice(device_) != hipSuccess) { err = "hipSetDevice failed"; return M0_ERR_HIP; }
+    (void)hipDeviceSynchronize();
+    for (void* p : ws_allocs_) (void)hipFree(p);
+    ws_allocs_.clear();
+    const size_t C = C_;
+    const size_t nb = Bp, nh = std::max(Bp, Mfc);
+    const size_t Cst = std::max<size_t>(C, 128);
+    auto H = [&](size_t elems) { return (_Float16*)dalloc(elems * 2, true); };
+    auto F = [&](size_t elems) { return (float*)dalloc(elems * 4, true); };
+    X0_ = H(nb * 64 * 32);
+    XA_ = H(nb * 64 * C); XB_ = H(nb * 64 * C); T1_ = H(nb * 64 * C); T2_ = H(nb * 64 * C);
+    QKV_ = H(nb * 64 * 3 * C); O_ = H(nb * 64 * C);
+    SX_ = F(nb * Cst * 2); S1_ = F(nb * Cst * 2); S2_ = F(nb * Cst * 2);
+    PH_ = H(nh * 64 * 64); PH2_ = H(nh * 64 * 64);
+    VH_ = H(nh * 64 * 128); VH2_ = H(nh * 64 * 128);
+    const size_t rp = cfg_.policy_factor_rank > 0 ? ceil_to(cfg_.policy_factor_rank, 32) : 32;
+    F1_ = H((size_t)Mfc * rp);
+    F2_ = H((size_t)Mfc * ceil_to(2 * C_, 32)); F3_ = H((size_t)Mfc * ceil_to(C_, 32)); F4_ = H((size_t)Mfc * ceil_to(C_, 32));
+    SH_ = H(nb * 64 * Cs_); SH2_ = H(nb * 64 * Cs_); SO_ = H(nb * 64 * 32);
+    VAL_ = F((size_t)Mfc * 32);
+    if (!X0_ || !XA_ || !XB_ || !T1_ || !T2_ || !QKV_ || !O_ || !SX_ || !S1_ || !S2_ || !PH_ || !PH2_ || !VH_ ||
+        !VH2_ || !F1_ || !F2_ || !F3_ || !F4_ || !SH_ || !SH2_ || !SO_ || !VAL_) {
+        err = "workspace hipMalloc failed";
+        wsB_ = wsM_ = 0;
+        return M0_ERR_HIP;
+    }
+    wsB_ = Bp; wsM_ = Mfc;
+    return M0_OK;
+}
+
+hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int Mrows, int Mvalid,
+                         const float* in_stats, const NormParams* in_norm, int pro_act, int epi_act,
+                         const _Float16* mul, float* out_stats, bool out_f32, float out_scale, hipStream_t st) {
+    GemmArgs a;
+    a.in = in; a.w = g.w; a.out = out;
+    a.in_stats = in_stats;
+    a.gamma = in_norm ? in_norm->gamma : nullptr;
+    a.beta = in_norm ? in_norm->beta : nullptr;
+    a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
+    a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
+    a.pro_act = pro_act; a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale;
+    return launch_conv_gemm(a, g.taps, st);
+}
+
+#define KCHK(x)                                                                           \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            err = std::string("kernel launch failed: ") + #x + ": " + hipGetErrorString(e_); \
+            return M0_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float* logits_dev, float* value_dev,
+                 float* ssl_dev, hipStream_t st, std::string& err) {
+    if (!finalized_) { err = "weights not finalized"; return M0_ERR_STATE; }
+    if (B <= 0) { err = "batch must be positive"; return M0_ERR_INVALID; }
+    TRY(ensure_workspace(B, err));
+    const int Bp = ceil_to(B, 4);
+    const int Mc = Bp * 64;
+    const int Mfc = ceil_to(B, 256);
+    const int act = cfg_.activation == M0_ACT_SILU ? ACT_SILU : ACT_RELU;
+    const int vact = cfg_.value_activation == M0_ACT_SILU ? ACT_SILU : (cfg_.value_activation == M0_ACT_LEAKY ? ACT_LEAKY : ACT_RELU);
+    const int C = C_;
+
+    const _Float16* x0 = nhwc_dev;
+    if (!x0) {
+        if (!planes_dev) { err = "no input"; return M0_ERR_INVALID; }
+        KCHK(launch_planes_to_nhwc(planes_dev, X0_, B, cfg_.planes, st));
+        x0 = X0_;
+    }
+    auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
+                  const float* pos, const NormParams* ln, _Float16* y, float* ost, int Cc, int boards) -> hipError_t {
+        EwArgs e;
+        memset(&e, 0, sizeof(e));
+        e.t = t; e.t_stats = tst;
+        if (gn) { e.gn_gamma = gn->gamma; e.gn_beta = gn->beta; }
+        if (se) { e.se_w1 = se->se_w1; e.se_b1 = se->se_b1; e.se_w2 = se->se_w2; e.se_b2 = se->se_b2; e.se_hidden = se->se_hidden; }
+        e.res = res; e.posenc = pos;
+        if (ln) { e.ln_g = ln->gamma; e.ln_b = ln->beta; }
+        e.y = y; e.out_stats = ost; e.C = Cc; e.act = act; e.stats_from_rounded = 0;
+        return launch_ew_board(e, boards, st);
+    };
+
+    // stem (resnet.py:314-318) + chess features (229-244)
+    KCHK(run_gemm(stem_, x0, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, cfg_.chess_features ? posenc_ : nullptr, nullptr, XA_, SX_, C, Bp));
+    _Float16* xa = XA_;
+    _Float16* xb = XB_;
+    if (cfg_.chess_features) {
+        if (cfg_.piece_square_tables) {
+            KCHK(run_gemm(pst_, xa, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+            std::swap(xa, xb);
+        }
+        KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+        KCHK(ew(T1_, S1_, &inter_n_, nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+        std::swap(xa, xb);
+    }
+    // tower
+    for (auto& L : tower_) {
+        if (L.kind == 0) {
+            const ResBlockW& r = res_[L.index];
+            // pre-activation block, resnet.py:45-51: GN+act fused into the consuming conv's prologue
+            KCHK(run_gemm(r.conv1, xa, T1_, Mc, Mc, SX_, &r.bn1, act, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, S1_, &r.bn2, act, 0, nullptr, S2_, false, 1.f, st));
+            KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+            std::swap(xa, xb);
+        } else {
+            if (L.skip) continue;
+            const AttnW& w = att_[L.index];
+            KCHK(run_gemm(w.qkv, xa, QKV_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
+            AttnArgs aa;
+            aa.qkv = QKV_; aa.rel_bias = w.rel_bias; aa.mask = mask_dev_; aa.o = O_;
+            aa.B = Bp; aa.H = cfg_.attention_heads; aa.C = C; aa.mix = cfg_.attention_unmasked_mix;
+            aa.inv_sqrt_d = 1.f / sqrtf((float)(C / cfg_.attention_heads));
+            KCHK(launch_attn_core(aa, st));
+            KCHK(run_gemm(w.proj, O_, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
+            KCHK(ew(T1_, nullptr, nullptr, nullptr, xa, nullptr, &w.ln, xb, SX_, C, Bp));
+            std::swap(xa, xb);
+        }
+    }
+    // policy head (resnet.py:699-711)
+    KCHK(run_gemm(ph_conv_, xa, PH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(PH_, S1_, &ph_n_, nullptr, nullptr, nullptr, nullptr, PH2_, nullptr, 64, Bp));
+    if (cfg_.policy_factor_rank > 0) {
+        KCHK(run_gemm(pfc1_, PH2_, F1_, Mfc, Mfc, nullptr, nullptr, 0, ACT_RELU, nullptr, nullptr, false, 1.f, st));
+        KCHK(run_gemm(pfc2_, F1_, logits_dev, Mfc, B, nullptr, nullptr, 0, 0, nullptr, nullptr, true, logit_scale_, st));
+    } else {
+        KCHK(run_gemm(pfc1_, PH2_, logits_dev, Mfc, B, nullptr, nullptr, 0, 0, nullptr, nullptr, true, logit_scale_, st));
+    }
+    // value head (resnet.py:721-734)
+    KCHK(run_gemm(vh0_, xa, VH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(VH_, S1_, &vh1_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, 128, Bp));
+    KCHK(run_gemm(vh3_, VH2_, VH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(VH_, S1_, &vh4_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, 128, Bp));
+    KCHK(run_gemm(vfc1_, VH2_, F2_, Mfc, Mfc, nullptr, nullptr, 0, vact, nullptr, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vfc2_, F2_, F3_, Mfc, Mfc, nullptr, nullptr, 0, vact, nullptr, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vgate_, F3_, F4_, Mfc, Mfc, nullptr, nullptr, 0, ACT_SIGMOID, F3_, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vfc3_, F4_, VAL_, Mfc, Mfc, nullptr, nullptr, 0, ACT_TANH, nullptr, nullptr, true, 1.f, st));
+    KCHK(hipMemcpy2DAsync(value_dev, 4, VAL_, 32 * 4, 4, B, hipMemcpyDeviceToDevice, st));
+    // ssl heads (resnet.py:738-745)
+    if (ssl_dev && !ssl_.empty()) {
+        const int ctot = ssl_channels_total();
+        int coff = 0;
+        for (auto& h : ssl_) {
+            KCHK(run_gemm(h.c0, xa, SH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(ew(SH_, S1_, &h.n, nullptr, nullptr, nullptr, nullptr, SH2_, nullptr, Cs_, Bp));
+            KCHK(run_gemm(h.c1, SH2_, SO_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
+            KCHK(launch_nhwc_to_nchw_f32(SO_, ssl_dev, B, 32, h.out_ch, ctot, coff, st));
+            coff += h.out_ch;
+        }
+    }
+    return M0_OK;
+}

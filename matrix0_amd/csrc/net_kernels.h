@@ -1,0 +1,67 @@
+// Launch interfaces of the network kernels (net_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_LEAKY = 3, ACT_SIGMOID = 4, ACT_TANH = 5 };
+
+struct GemmArgs {
+    const _Float16* in;      // [Mrows][Cin]
+    const _Float16* w;       // packed [taps][Cin/KC][Npad][KC]
+    void* out;               // [Mrows][ldo] fp16 | f32
+    const float* in_stats;   // [Mrows/64][Cin][2] (sum, sumsq) -> GroupNorm16 prologue ; null = none
+    const float* gamma;      // [Cin]
+    const float* beta;       // [Cin]
+    const float* bias;       // [N] or null
+    const _Float16* mul;     // [Mrows][ldo] or null
+    float* out_stats;        // [Mrows/64][N][2] or null
+    int Mrows;               // multiple of 256
+    int Mvalid;              // rows actually stored
+    int Cin;                 // multiple of KC
+    int N;                   // valid output columns
+    int Npad;                // packed columns (multiple of the N tile)
+    int ldo;                 // output row stride (elements)
+    int pro_act;
+    int epi_act;
+    int out_f32;
+    float out_scale;
+};
+
+struct EwArgs {
+    const _Float16* t;       // [B][64][C]
+    const float* t_stats;    // [B][C][2]
+    const float* gn_gamma;   // GroupNorm16 + act when non-null
+    const float* gn_beta;
+    const float* se_w1;      // [C][Hd] (transposed), SE gate when non-null (and gn null)
+    const float* se_b1;
+    const float* se_w2;      // [C][Hd]
+    const float* se_b2;
+    const _Float16* res;     // [B][64][C] or null
+    const float* posenc;     // [64][C] or null
+    const float* ln_g;       // LayerNorm over C when non-null
+    const float* ln_b;
+    _Float16* y;             // [B][64][C]
+    float* out_stats;        // [B][C][2] or null
+    int C;
+    int se_hidden;
+    int act;
+    int stats_from_rounded;
+};
+
+struct AttnArgs {
+    const _Float16* qkv;     // [B][64][3C]
+    const float* rel_bias;   // [H][64][64] or null
+    const uint64_t* mask;    // [64] bit j of word i = key j visible from query i
+    _Float16* o;             // [B][64][C]
+    int B, H, C;
+    float mix;
+    float inv_sqrt_d;
+};
+
+hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st);
+int conv_gemm_tile_n(int Cin, int Npad);
+int conv_gemm_kc(int Cin, int Npad);
+hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st);
+hipError_t launch_attn_core(const AttnArgs& a, hipStream_t st);
+hipError_t launch_planes_to_nhwc(const float* x, void* y, int B, int P, hipStream_t st);
+hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int B, int ld, int n, int ctot, int coff, hipStream_t st);

@@ -1,0 +1,530 @@
+// MI355X (gfx950 / CDNA4) kernels for the R24-320 policy/value network forward.
+//
+// Replaces the reference's torch forward (azchess/model/resnet.py:656-760) on the
+// self-play hot path.  Data layout in HBM: every activation is "NHWC"
+// [board][64 squares][C] fp16, square n = row*8+col of the reference tensor
+// (row 0 = rank 8).  A board's 64 squares are the 64 rows of one wave's MFMA
+// tile, so every per-board reduction (GroupNorm statistics, SE pooling) is
+// wave-local.
+//
+// Kernels:
+//   conv_gemm_kernel<TAPS,WN,NT,KC>  implicit-GEMM 3x3 / 1x1 conv and FC layers
+//       on v_mfma_f32_32x32x16_f16, fp32 accumulate.  WG tile = 256 rows
+//       (4 boards) x WN*NT*32 output channels; input staged once per K-chunk in
+//       a zero-bordered 10x10 halo image in LDS and re-read for all 9 taps.
+//       Optional prologue: GroupNorm(+activation) of the *input* applied while
+//       staging (statistics come from the producer's epilogue).
+//       Epilogue: bias / activation / multiply / scale, fp16 or fp32 store,
+//       per-(board,channel) sum and sum-of-squares for the next norm.
+//   ew_board_kernel   per-board elementwise glue: GN+act, SE gate, residual add,
+//       positional encoding, LayerNorm over C, output statistics.
+//   attn_core_kernel  ChessAttention scores/softmax/PV for one (board, head).
+//   planes_to_nhwc_kernel  f32 [B,19,8,8] -> fp16 [B,64,32].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "net_kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_LEAKY: return v > 0.f ? v : 0.05f * v;
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv_gemm
+// ---------------------------------------------------------------------------
+template <int TAPS, int WN, int NT, int KC>
+__global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
+    constexpr int NB = WN * NT * 32;      // output channels per workgroup
+    constexpr int NTHR = 256 * WN;
+    constexpr int AST = KC + 8;           // LDS row stride in halfs (pad: conflict-free b128 reads)
+    constexpr int APIX = (TAPS == 9) ? 100 : 64;
+    constexpr int A_ELEMS = 4 * APIX * AST;
+    constexpr int W_ELEMS = NB * AST;
+    constexpr int A_PIECES = 4 * 64 * KC / 8;             // 16-byte pieces per A chunk
+    constexpr int W_PIECES = NB * KC / 8;
+    constexpr int A_PER = (A_PIECES + NTHR - 1) / NTHR;
+    constexpr int W_PER = (W_PIECES + NTHR - 1) / NTHR;
+    constexpr int K8 = KC / 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* A_lds = reinterpret_cast<_Float16*>(smem);
+    _Float16* W_lds = A_lds + A_ELEMS;                    // 2 buffers
+    float* gstat = reinterpret_cast<float*>(W_lds + 2 * W_ELEMS);  // [4 boards][Cin/16][2] mean,rstd
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % 4;              // board within the tile
+    const int wn = wave / 4;              // N half
+    const int m0 = blockIdx.x * 256;      // first row
+    const int n0 = blockIdx.y * NB;
+    const int Cin = a.Cin;
+    const int nchunk = Cin / KC;
+    const int Npad = a.Npad;
+    const bool pro = a.in_stats != nullptr;
+
+    // zero the halo image once (borders stay zero for the whole kernel)
+    if (TAPS == 9) {
+        for (int i = tid; i < A_ELEMS / 8; i += NTHR)
+            reinterpret_cast<uint4*>(A_lds)[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (pro) {
+        // GroupNorm statistics of the input: group = 16 channels x 64 squares
+        const int ngrp = Cin / 16;
+        const int board0 = m0 / 64;
+        for (int i = tid; i < 4 * ngrp; i += NTHR) {
+            int b = i / ngrp, g = i % ngrp;
+            const float* st = a.in_stats + ((size_t)(board0 + b) * Cin + g * 16) * 2;
+            float s = 0.f, ss = 0.f;
+            for (int c = 0; c < 16; ++c) { s += st[2 * c]; ss += st[2 * c + 1]; }
+            float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            gstat[2 * i] = mean;
+            gstat[2 * i + 1] = rsqrtf(var + 1e-5f);
+        }
+    }
+    __syncthreads();
+
+    float16v acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // per-lane LDS base of its two A rows (squares lane&31 and 32+(lane&31) of board wm)
+    int apix[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int px = mi * 32 + (lane & 31);
+        if (TAPS == 9) apix[mi] = wm * 100 + ((px >> 3) + 1) * 10 + (px & 7) + 1;
+        else apix[mi] = wm * 64 + px;
+    }
+    const int khalf = 8 * (lane >> 5);
+
+    uint4 areg[A_PER];
+    uint4 wreg[W_PER];
+
+    auto load_A = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int p = tid + i * NTHR;
+            if (A_PIECES % NTHR == 0 || p < A_PIECES) {
+                int row = p / K8, c8 = p % K8;
+                areg[i] = *reinterpret_cast<const uint4*>(a.in + (size_t)(m0 + row) * Cin + chunk * KC + c8 * 8);
+            }
+        }
+    };
+    auto store_A = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int p = tid + i * NTHR;
+            if (A_PIECES % NTHR == 0 || p < A_PIECES) {
+                int row = p / K8, c8 = p % K8;
+                int b = row >> 6, px = row & 63;
+                uint4 v = areg[i];
+                if (pro) {
+                    int c = chunk * KC + c8 * 8;
+                    const float mean = gstat[2 * (b * (Cin / 16) + (c >> 4))];
+                    const float rstd = gstat[2 * (b * (Cin / 16) + (c >> 4)) + 1];
+                    _Float16* h = reinterpret_cast<_Float16*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float x = (float)h[j];
+                        float y = (x - mean) * rstd * a.gamma[c + j] + a.beta[c + j];
+                        h[j] = (_Float16)act_apply(y, a.pro_act);
+                    }
+                }
+                int pix = (TAPS == 9) ? (b * 100 + ((px >> 3) + 1) * 10 + (px & 7) + 1) : row;
+                *reinterpret_cast<uint4*>(A_lds + pix * AST + c8 * 8) = v;
+            }
+        }
+    };
+    auto load_W = [&](int step) {
+        // step = chunk*TAPS + tap ; packed layout [tap][chunk][Npad][KC]
+        int chunk = step / TAPS, tap = step % TAPS;
+        const _Float16* src = a.w + ((size_t)(tap * nchunk + chunk) * Npad + n0) * KC;
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            int p = tid + i * NTHR;
+            if (W_PIECES % NTHR == 0 || p < W_PIECES)
+                wreg[i] = *reinterpret_cast<const uint4*>(src + (size_t)p * 8);
+        }
+    };
+    auto store_W = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            int p = tid + i * NTHR;
+            if (W_PIECES % NTHR == 0 || p < W_PIECES) {
+                int n = p / K8, k8 = p % K8;
+                *reinterpret_cast<uint4*>(W_lds + buf * W_ELEMS + n * AST + k8 * 8) = wreg[i];
+            }
+        }
+    };
+
+    const int nsteps = nchunk * TAPS;
+    load_A(0);
+    load_W(0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int chunk = s / TAPS, tap = s % TAPS;
+        if (tap == 0) {
+            if (s > 0) __syncthreads();   // previous chunk's reads of A_lds are done
+            store_A(chunk);
+        }
+        store_W(s & 1);
+        __syncthreads();
+        if (s + 1 < nsteps) {
+            load_W(s + 1);
+            if ((s + 1) % TAPS == 0) load_A((s + 1) / TAPS);
+        }
+        const int tapoff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
+        const _Float16* Wb = W_lds + (s & 1) * W_ELEMS + (wn * NT * 32 + (lane & 31)) * AST + khalf;
+#pragma unroll
+        for (int kk = 0; kk < KC / 16; ++kk) {
+            half8 af[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                af[mi] = *reinterpret_cast<const half8*>(A_lds + (apix[mi] + tapoff) * AST + kk * 16 + khalf);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 32 * AST + kk * 16);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf, acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    const int N = a.N;
+    const int ldo = a.ldo;
+    const int rowbase = m0 + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = n0 + wn * NT * 32 + ni * 32 + (lane & 31);
+        const bool colok = col < N;
+        const float bias = (a.bias != nullptr && colok) ? a.bias[col] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                float v = acc[mi][ni][r] + bias;
+                v = act_apply(v, a.epi_act);
+                if (a.mul != nullptr && colok) v *= (float)a.mul[(size_t)row * ldo + col];
+                v *= a.out_scale;
+                s += v; ss += v * v;
+                if (colok && row < a.Mvalid) {
+                    if (a.out_f32) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
+                    else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
+                }
+            }
+        }
+        if (a.out_stats != nullptr) {
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            if (lane < 32 && colok) {
+                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * N + col) * 2;
+                st[0] = s; st[1] = ss;
+            }
+        }
+    }
+}
+
+template <int TAPS, int WN, int NT, int KC>
+static size_t conv_gemm_lds(int Cin) {
+    constexpr int NB = WN * NT * 32;
+    constexpr int AST = KC + 8;
+    constexpr int APIX = (TAPS == 9) ? 100 : 64;
+    return (size_t)(4 * APIX * AST + 2 * NB * AST) * 2 + (size_t)4 * (Cin / 16) * 2 * 4 + 64;
+}
+
+template <int TAPS, int WN, int NT, int KC>
+static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
+    constexpr int NB = WN * NT * 32;
+    size_t lds = conv_gemm_lds<TAPS, WN, NT, KC>(a.Cin);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<TAPS, WN, NT, KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(a.Mrows / 256, a.Npad / NB);
+    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, WN, NT, KC>), grid, dim3(256 * WN), lds, st, a);
+    return hipGetLastError();
+}
+
+int conv_gemm_tile_n(int Cin, int Npad) {
+    return (Npad % 320 == 0 && Cin % 64 == 0) ? 320 : 32;
+}
+int conv_gemm_kc(int Cin, int Npad) {
+    return (Npad % 320 == 0 && Cin % 64 == 0) ? 64 : 32;
+}
+
+hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
+    if (a.Mrows % 256 != 0 || a.Cin % 32 != 0 || a.Npad % 32 != 0) return hipErrorInvalidValue;
+    const bool big = conv_gemm_tile_n(a.Cin, a.Npad) == 320;
+    if (taps == 9) {
+        if (big) return launch_conv_gemm_t<9, 2, 5, 64>(a, st);
+        return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
+    } else if (taps == 1) {
+        if (big) return launch_conv_gemm_t<1, 2, 5, 64>(a, st);
+        return launch_conv_gemm_t<1, 1, 1, 32>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// ew_board: one workgroup (256 threads) per board, tensor [64][C] fp16.
+//   v = t
+//   if t_stats:  v = act(GroupNorm16(v))             (gamma/beta, act)
+//   if se_w1:    v *= gate[c]   gate = sigmoid(W2 act(W1 pool + b1) + b2), pool from t_stats sums
+//   if res:      v += res
+//   if posenc:   v += posenc[n][c]
+//   if ln_g:     v = LayerNorm_C(v)
+//   y = v ; out_stats = per-channel (sum, sumsq) over the 64 squares
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ew_board_kernel(EwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C;
+    float* sc = reinterpret_cast<float*>(smem);        // [C] scale (GN) or gate (SE)
+    float* sh = sc + C;                                // [C] shift
+    float* red = sh + C;                               // [4 waves][C][2] stats partials
+    float* hid = red + 4 * C * 2;                      // [hidden]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const _Float16* t = a.t + (size_t)b * 64 * C;
+    const float* tst = a.t_stats ? a.t_stats + (size_t)b * C * 2 : nullptr;
+
+    if (a.gn_gamma != nullptr) {
+        for (int c = tid; c < C; c += 256) {
+            int g0 = (c >> 4) << 4;
+            float s = 0.f, ss = 0.f;
+            for (int j = 0; j < 16; ++j) { s += tst[2 * (g0 + j)]; ss += tst[2 * (g0 + j) + 1]; }
+            float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            float rstd = rsqrtf(var + 1e-5f);
+            float g = a.gn_gamma[c] * rstd;
+            sc[c] = g;
+            sh[c] = a.gn_beta[c] - mean * g;
+        }
+    } else if (a.se_w1 != nullptr) {
+        // squeeze-excite gate (resnet.py:59-68); pooled mean from the conv epilogue sums
+        for (int c = tid; c < C; c += 256) sh[c] = tst[2 * c] * (1.f / 64.f);
+        __syncthreads();
+        const int Hd = a.se_hidden;
+        for (int j = tid; j < Hd; j += 256) {
+            float s = a.se_b1[j];
+            for (int c = 0; c < C; ++c) s += a.se_w1[(size_t)c * Hd + j] * sh[c];   // w1 stored [C][Hd]
+            hid[j] = act_apply(s, a.act);
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = a.se_b2[c];
+            for (int j = 0; j < Hd; ++j) s += a.se_w2[(size_t)c * Hd + j] * hid[j];
+            sc[c] = 1.f / (1.f + __expf(-s));
+        }
+    }
+    __syncthreads();
+
+    const bool gn = a.gn_gamma != nullptr;
+    const bool se = (!gn) && a.se_w1 != nullptr;
+    const _Float16* res = a.res ? a.res + (size_t)b * 64 * C : nullptr;
+    _Float16* y = a.y + (size_t)b * 64 * C;
+    const int nper = (C + 63) / 64;      // channels per lane (strided by 64), <= 8
+    float csum[8], csq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { csum[i] = 0.f; csq[i] = 0.f; }
+    for (int n = wave; n < 64; n += 4) {
+        float v[8];
+        float rs = 0.f, rss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int c = lane + 64 * i;
+            v[i] = 0.f;
+            if (i < nper && c < C) {
+                float x = (float)t[n * C + c];
+                if (gn) x = act_apply(x * sc[c] + sh[c], a.act);
+                else if (se) x *= sc[c];
+                if (res) x += (float)res[n * C + c];
+                if (a.posenc) x += a.posenc[n * C + c];
+                v[i] = x; rs += x; rss += x * x;
+            }
+        }
+        if (a.ln_g != nullptr) {
+            for (int o = 32; o > 0; o >>= 1) { rs += __shfl_xor(rs, o); rss += __shfl_xor(rss, o); }
+            float mean = rs / (float)C;
+            float var = rss / (float)C - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int c = lane + 64 * i;
+                if (i < nper && c < C) v[i] = (v[i] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int c = lane + 64 * i;
+            if (i < nper && c < C) {
+                _Float16 h = (_Float16)v[i];
+                y[n * C + c] = h;
+                float q = a.stats_from_rounded ? (float)h : v[i];
+                csum[i] += q; csq[i] += q * q;
+            }
+        }
+    }
+    if (a.out_stats != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int c = lane + 64 * i;
+            if (i < nper && c < C) { red[(wave * C + c) * 2] = csum[i]; red[(wave * C + c) * 2 + 1] = csq[i]; }
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f, ss = 0.f;
+            for (int w = 0; w < 4; ++w) { s += red[(w * C + c) * 2]; ss += red[(w * C + c) * 2 + 1]; }
+            a.out_stats[((size_t)b * C + c) * 2] = s;
+            a.out_stats[((size_t)b * C + c) * 2 + 1] = ss;
+        }
+    }
+}
+
+hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st) {
+    if (a.C > 512) return hipErrorInvalidValue;
+    size_t lds = (size_t)(2 * a.C + 8 * a.C + (a.se_hidden > 0 ? a.se_hidden : 1)) * 4;
+    hipLaunchKernelGGL(ew_board_kernel, dim3(boards), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// attn_core: ChessAttention.forward lines 142-179 for one (board, head) per wave.
+// qkv [B][64][3C] fp16, channel = (t*H + h)*D + d, D == 16.  Lane = query square.
+//   S = QK^T/sqrt(D) (+rel_bias[h]) clamp +-50 ; masked branch fill -1e4 ;
+//   out = (1-mix)*softmax(S_masked)V + mix*softmax(S)V     (mix in (0,1))
+//   mix >= 1: masked only ; mix <= 0: unmasked only.
+// o [B][64][C] fp16 with channel h*D+d.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
+    __shared__ float Ks[4][64][17];
+    __shared__ float Vs[4][64][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, C = a.C;
+    const long job = (long)blockIdx.x * 4 + wave;
+    const long njobs = (long)a.B * H;
+    const bool live = job < njobs;
+    const int b = live ? (int)(job / H) : 0, h = live ? (int)(job % H) : 0;
+    const _Float16* base = a.qkv + (size_t)b * 64 * 3 * C;
+    float q[16];
+    {
+        const _Float16* qp = base + (size_t)lane * 3 * C + (0 * H + h) * 16;
+        const _Float16* kp = base + (size_t)lane * 3 * C + (1 * H + h) * 16;
+        const _Float16* vp = base + (size_t)lane * 3 * C + (2 * H + h) * 16;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            q[d] = (float)qp[d];
+            Ks[wave][lane][d] = (float)kp[d];
+            Vs[wave][lane][d] = (float)vp[d];
+        }
+    }
+    __syncthreads();
+    const uint64_t mrow = a.mask[lane];
+    const float* rb = a.rel_bias ? a.rel_bias + ((size_t)h * 64 + lane) * 64 : nullptr;
+    // Scores are clamped to [-50,50], so exp() needs no max subtraction in fp32, and the
+    // masked branch's -1e4 fill underflows to exactly 0 (the query's own square is always
+    // visible, so the masked row maximum is >= -50): e_masked = visible ? e : 0.
+    float su = 0.f, sm = 0.f;
+    float ou[16], om[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { ou[d] = 0.f; om[d] = 0.f; }
+#pragma unroll 4
+    for (int j = 0; j < 64; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d += q[k] * Ks[wave][j][k];
+        d *= a.inv_sqrt_d;
+        if (rb) d += rb[j];
+        d = fminf(fmaxf(d, -50.f), 50.f);
+        const float eu = __expf(d);
+        const float em = ((mrow >> j) & 1ull) ? eu : 0.f;
+        su += eu; sm += em;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = Vs[wave][j][k];
+            ou[k] += eu * v; om[k] += em * v;
+        }
+    }
+    if (live) {
+        float wu, wmk;
+        if (a.mix > 0.f && a.mix < 1.f) { wmk = (1.f - a.mix) / sm; wu = (1.f - (1.f - a.mix)) / su; }
+        else if (a.mix >= 1.f) { wmk = 1.f / sm; wu = 0.f; }
+        else { wmk = 0.f; wu = 1.f / su; }
+        _Float16* op = a.o + ((size_t)b * 64 + lane) * C + h * 16;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) op[d] = (_Float16)(wmk * om[d] + wu * ou[d]);
+    }
+}
+
+hipError_t launch_attn_core(const AttnArgs& a, hipStream_t st) {
+    long njobs = (long)a.B * a.H;
+    hipLaunchKernelGGL(attn_core_kernel, dim3((unsigned)((njobs + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// planes f32 [B][P][64] -> fp16 [B][64][32] (channels >= P zero)
+// ---------------------------------------------------------------------------
+__global__ void planes_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int B, int P) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * 64 * 32;
+    if (i >= total) return;
+    int c = (int)(i % 32);
+    long bn = i / 32;
+    int n = (int)(bn % 64);
+    long b = bn / 64;
+    float v = (c < P) ? x[(b * P + c) * 64 + n] : 0.f;
+    y[i] = (_Float16)v;
+}
+
+hipError_t launch_planes_to_nhwc(const float* x, void* y, int B, int P, hipStream_t st) {
+    long total = (long)B * 64 * 32;
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x,
+                       reinterpret_cast<_Float16*>(y), B, P);
+    return hipGetLastError();
+}
+
+// fp16 [B][64][ld] (first n channels) -> f32 [B][ctot][64] at channel offset coff
+// (SSL head outputs, NCHW for the boundary)
+__global__ void nhwc_to_nchw_f32_kernel(const _Float16* __restrict__ x, float* __restrict__ y, int B, int ld, int n,
+                                        int ctot, int coff) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * n * 64;
+    if (i >= total) return;
+    int sq = (int)(i % 64);
+    long bc = i / 64;
+    int c = (int)(bc % n);
+    long b = bc / n;
+    y[(b * ctot + coff + c) * 64 + sq] = (float)x[(b * 64 + sq) * ld + c];
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int B, int ld, int n, int ctot, int coff, hipStream_t st) {
+    long total = (long)B * n * 64;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const _Float16*>(x), y, B, ld, n, ctot, coff);
+    return hipGetLastError();
+}

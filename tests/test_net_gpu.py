@@ -1,0 +1,93 @@
+"""GPU parity: HIP network forward (through the C-ABI / infer_np seam) vs the fp32 oracle
+and vs the reference golden vectors.
+
+Tolerances (fp16 MFMA operands, fp32 accumulate, fp16 activations in HBM vs fp32 reference;
+SURVEY App. A.3): max|dlogit| <= 5e-2, |dv| <= 1e-2, KL(softmax) <= 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_ref
+from tests.golden_util import load_net_golden
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 5e-2
+VALUE_TOL = 1e-2
+
+
+def _kl(p_ref, p):
+    a = torch.log_softmax(torch.from_numpy(p_ref), -1)
+    b = torch.log_softmax(torch.from_numpy(p), -1)
+    return float((a.exp() * (a - b)).sum(-1).max())
+
+
+@pytest.mark.parametrize("name", ["gn_silu_preact", "gn_dense_leaky", "stride2"])
+def test_hip_net_matches_reference_golden(name):
+    from matrix0_amd.backend import M0Backend
+    cfg, sd, x, p_ref, v_ref, ssl_ref = load_net_golden(name)
+    be = M0Backend.from_state_dict(cfg, sd)
+    if ssl_ref:
+        p, v, ssl = be.infer_np_ssl(x)
+    else:
+        p, v = be.infer_np(x)
+        ssl = {}
+    assert p.shape == p_ref.shape and v.shape == v_ref.shape
+    assert np.abs(p - p_ref).max() <= LOGIT_TOL
+    assert np.abs(v - v_ref).max() <= VALUE_TOL
+    assert _kl(p_ref, p) <= 1e-3
+    for t, ref in ssl_ref.items():
+        assert np.abs(ssl[t] - ref).max() <= 5e-2, t
+    assert be.param_count() == sum(int(np.prod(t.shape)) for t in sd.values())
+
+
+def test_unsupported_config_fails_loudly():
+    from matrix0_amd.backend import M0Backend
+    cfg, sd, *_ = load_net_golden("bn_relu_postact")
+    with pytest.raises(RuntimeError, match="unsupported network config"):
+        M0Backend(cfg)
+
+
+def _r24_cfg():
+    return dict(planes=19, channels=320, blocks=24, attention_heads=20, policy_size=4672, norm="group",
+                activation="silu", preact=True, policy_factor_rank=128, self_supervised=True,
+                ssl_tasks=["piece", "threat", "pin", "fork", "control"])
+
+
+def test_r24_320_vs_oracle():
+    """Full-size benchmark network, random-init weights, vs the fp32 CPU oracle."""
+    from matrix0_amd.backend import M0Backend
+    cfg = _r24_cfg()
+    sd = net_ref.random_state_dict(cfg, seed=0)
+    be = M0Backend.from_state_dict(cfg, sd)
+    assert be.param_count() == 57_562_210
+    assert abs(be.flops_per_position(False) / 6.3085e9 - 1) < 1e-3
+    assert abs(be.flops_per_position(True) / 6.3417e9 - 1) < 1e-3
+    g = torch.Generator().manual_seed(5)
+    B = 6   # not a multiple of the 4-board tile: exercises padding
+    x = torch.zeros(B, 19, 8, 8)
+    x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+    x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+    x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+    p_ref, v_ref, ssl_ref = net_ref.forward(sd, cfg, x, return_ssl=True)
+    p, v, ssl = be.infer_np_ssl(x.numpy())
+    assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
+    assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
+    assert _kl(p_ref.numpy(), p) <= 1e-3
+    for t in ssl_ref:
+        assert np.abs(ssl[t] - ssl_ref[t].numpy()).max() <= 1e-1, t
+    # single position + repeated call determinism
+    p1, v1 = be.infer_np(x[0].numpy())
+    assert np.array_equal(p1[0], p[0]) and v1[0] == v[0]
+
+
+def test_infer_np_rejects_bad_shape_and_nan():
+    from matrix0_amd.backend import M0Backend
+    cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
+    be = M0Backend.from_state_dict(cfg, sd)
+    with pytest.raises(ValueError):
+        be.infer_np(np.zeros((2, 18, 8, 8), np.float32))
+    bad = x.copy()
+    bad[0, 0, 0, 0] = np.nan
+    with pytest.raises(ValueError):
+        be.infer_np(bad)

@@ -40,7 +40,7 @@ CASES = {
                             norm="group", activation="silu", preact=True, policy_factor_rank=16,
                             self_supervised=True,
                             ssl_tasks=["piece", "threat", "pin", "fork", "control"]), 3),
-    "gn_dense_leaky": (dict(planes=19, channels=32, blocks=3, attention_heads=4, policy_size=4672,
+    "gn_dense_leaky": (dict(planes=19, channels=32, blocks=3, attention_heads=2, policy_size=4672,
                             norm="group", activation="silu", preact=True, policy_factor_rank=0,
                             value_activation="leaky_relu", attention_relbias=False,
                             self_supervised=False), 2),
@@ -48,7 +48,7 @@ CASES = {
                              norm="batch", activation="relu", preact=False, se=False,
                              attention_every_k=2, policy_factor_rank=8, self_supervised=True,
                              ssl_tasks=["piece"]), 2),
-    "stride2": (dict(planes=19, channels=48, blocks=6, attention_heads=3, policy_size=4672,
+    "stride2": (dict(planes=19, channels=64, blocks=6, attention_heads=4, policy_size=4672,
                      norm="group", activation="silu", preact=True, policy_factor_rank=16,
                      infer_attention_stride=2, value_activation="leaky_relu",
                      self_supervised=True, ssl_tasks=["piece", "control"]), 2),
