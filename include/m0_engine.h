@@ -4,18 +4,18 @@
  *
  *   1. inference backend  obj.infer_np(np.float32[B,19,8,8]) -> (np.float32[B,4672], np.float32[B])
  *        azchess/mcts.py:618-621, 1021-1023; azchess/selfplay/inference.py:585-645 (InferenceClient.infer_np)
- *        -> m0_infer()
+ *        -> m0_net_infer
  *   2. worker entry       selfplay_worker(proc_id, cfg_dict, ckpt_path, games, q, shared_memory_resource)
  *        azchess/selfplay/internal.py:94-95 (called from orchestrator.py:494, selfplay/__main__.py:68)
- *        -> m0_selfplay_start() / m0_selfplay_step() / m0_selfplay_poll()
+ *        -> m0_selfplay_create / m0_selfplay_step / m0_selfplay_poll
  *
  *   plus the pure functions of azchess/encoding.py, exposed position-wise for parity tests and
- *   for callers that keep python-chess:  m0_encode_fen(), m0_legal_mask_fen(), m0_move_to_index_fen().
+ *   for callers that keep python-chess:  m0_encode_fens, m0_move_to_index_fen.
  *
  * Conventions: every function returns 0 on success or a negative code; the message is
  * available from m0_last_error() (thread-local).  No exception crosses the ABI.  All buffers
  * are caller-allocated host memory unless a parameter says "_dev".  Handles are opaque.
- * The library never falls back to a CPU path: without a HIP device m0_create() fails.
+ * The library never falls back to a CPU path: without a HIP device m0_net_create fails.
  */
 #ifndef M0_ENGINE_H
 #define M0_ENGINE_H
@@ -96,6 +96,109 @@ double m0_net_flops_per_position(const m0_net* net, int with_ssl);
 /* Timed forward on synthetic resident inputs (bench/roofline): runs `iters` forwards of batch B on the
  * net's stream and returns the mean milliseconds per forward measured with HIP events on that stream. */
 int m0_net_bench_forward(m0_net* net, int B, int iters, int with_ssl, float* ms_per_forward);
+
+
+/* ---- position-wise azchess/encoding.py on the device (batched) ----
+ * encode_board (encoding.py:11-46), MoveEncoder.get_legal_actions (:231-243), move_to_index (:80-150).
+ * fens: n NUL-terminated strings.  Outputs nullable:
+ *   planes f32 [n,19,8,8]; mask u8 [n,4672]; nlegal i32 [n];
+ *   moves u16 [n,256] (from | to<<6 | promo<<12, promo 1..4 = N,B,R,Q) in legal_moves order; idx i32 [n,256]. */
+int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes, uint8_t* mask, int32_t* nlegal,
+                   uint16_t* moves, int32_t* idx);
+/* move_to_index for one (fen, uci): raises M0_ERR_INVALID for an illegal move (ValueError in the reference). */
+int m0_move_to_index_fen(int hip_device, const char* fen, const char* uci, int32_t* idx);
+
+/* ---- search + self-play (seam 2) ---- */
+/* MCTSConfig (azchess/mcts.py:61-107) + the selfplay/draw keys of config.yaml the worker reads
+ * (azchess/selfplay/internal.py:269-310, 348-381; azchess/draw.py). */
+typedef struct m0_selfplay_cfg {
+    /* mcts */
+    int num_simulations;          /* selfplay.num_simulations overrides mcts.num_simulations (internal.py:291) */
+    double cpuct, cpuct_start, cpuct_end;
+    int cpuct_plies;              /* <=0 or missing start/end: constant cpuct */
+    int use_c_base; double cpuct_c_base, cpuct_c_init;
+    double dirichlet_alpha, dirichlet_frac;
+    int dirichlet_plies;          /* <0: always */
+    double selection_jitter, fpu_reduction, draw_penalty, virtual_loss;
+    int legal_softmax, enable_entropy_noise, no_instant_backtrack, value_from_white;
+    int inference_batch_size;     /* leaves collected per tree and step (<= 96 in the reference) */
+    double playout_random_frac;
+    /* selfplay */
+    int max_game_len, min_resign_plies, opening_random_plies;
+    double resign_threshold; int resign_window, resign_consecutive_bad; double resign_min_entropy, resign_value_margin;
+    double temperature_start, temperature_end; int temperature_moves;
+    int low_visit_threshold;
+    /* draw adjudication (draw.py) */
+    int draw_enabled, draw_min_plies, draw_window, draw_min_unique, draw_halfmove_cap, draw_material_threshold, draw_stalemate;
+    /* engine */
+    int concurrent_games;         /* trees resident on this GPU */
+    int total_games;              /* games to play (<=0: unbounded, slots restart forever) */
+    int first_game_index;         /* global index of this engine's first game (multi-GPU sharding) */
+    int arena_nodes;              /* nodes per arena half and game (0 = default) */
+    uint64_t seed;                /* cfg["seed"] (1234) */
+    int virtual_loss_active;      /* 1 = apply mcts.py:889-890/922-923 as written (the reference never does) */
+    int ssl_in_forward;           /* run the SSL heads in every leaf evaluation (BASELINE config 4) */
+    int record_games;             /* keep s/pi/legal_mask per ply for m0_selfplay_poll */
+} m0_selfplay_cfg;
+
+typedef struct m0_selfplay m0_selfplay;
+
+typedef struct m0_selfplay_stats {
+    uint64_t steps, evals, sims, plies, games_finished, games_started;
+    double ms_total, ms_net, ms_tree, ms_host;   /* accumulated wall (host) and device (HIP events) times */
+    uint64_t arena_overflows;
+    int active_games;
+} m0_selfplay_stats;
+
+/* One finished game = one NPZ shard of the reference (selfplay/internal.py:628-651). Arrays stay valid
+ * until m0_game_record_free. */
+typedef struct m0_game_record {
+    int game_index, moves, resigned, resigner /*0 none 1 W 2 B*/, draw, total_plies /*incl. opening*/;
+    float result;                 /* z, White POV */
+    float avg_policy_entropy, avg_sims;
+    double secs;
+    const float* s;               /* [T,19,8,8] */
+    const float* pi;              /* [T,4672] */
+    const float* z;               /* [T] */
+    const uint8_t* legal_mask;    /* [T,4672] */
+    const float* search_values;   /* [T] root_q per ply */
+    const uint16_t* played;       /* [total_plies] moves incl. opening plies */
+    void* owner;
+} m0_game_record;
+
+m0_selfplay* m0_selfplay_create(m0_net* net, const m0_selfplay_cfg* cfg);
+void m0_selfplay_destroy(m0_selfplay* sp);
+/* Run `steps` search steps (select -> network -> expand/backup over all resident games), playing moves,
+ * finishing and restarting games as searches complete. */
+int m0_selfplay_step(m0_selfplay* sp, int steps);
+int m0_selfplay_stats_get(m0_selfplay* sp, m0_selfplay_stats* out);
+/* Pop one finished game; returns 1 if a record was written, 0 if none pending, <0 on error. */
+int m0_selfplay_poll(m0_selfplay* sp, m0_game_record* out);
+void m0_game_record_free(m0_game_record* rec);
+/* 1 while games remain to be played or are in flight. */
+int m0_selfplay_running(m0_selfplay* sp);
+
+/* ---- split-step search (external evaluator / parity tests): net may be NULL ----
+ * m0_search_begin: reset slot g to `fen` (history-less), sims simulations, optional Dirichlet.
+ * m0_search_select: run select for all active slots; returns rows; planes f32 [rows,19,8,8] of the leaves.
+ * m0_search_expand: feed logits f32 [rows,4672] and values f32 [rows]; expand + backup.
+ * m0_search_result: visits/moves/indices/priors/q of the root children after the search. */
+int m0_search_begin(m0_selfplay* sp, int g, const char* fen, int sims, int dirichlet, int game_uid);
+int m0_search_select(m0_selfplay* sp, int* rows, float* planes, int max_rows);
+int m0_search_expand(m0_selfplay* sp, const float* logits, const float* values, int rows);
+int m0_search_result(m0_selfplay* sp, int g, int* nchild, int32_t* child_n, uint16_t* child_mv, int32_t* child_idx,
+                     double* child_prior, double* child_q, double* root_q, int* root_n, int* finished);
+/* play child slot `slot` of the finished search in g and keep its subtree (tree reuse across moves) */
+int m0_search_advance(m0_selfplay* sp, int g, int slot, int sims, int dirichlet);
+
+/* ---- host decision functions (selfplay/internal.py), exposed for parity tests ---- */
+int m0_sample_move_index(const int32_t* visits, int n, double temperature, double u);
+int m0_playout_cap(int sims, double frac, double u);
+double m0_temperature_for(int fullmove_number, double t_start, double t_end, int t_moves);
+/* position + move list -> flags: bit0 game_over, bit1 game_over(claim_draw), bit2 adjudicate_draw(cfg of sp),
+ * bit3 checkmate, bit4 stalemate, bit5 insufficient, bit6 can_claim_fifty, bit7 is_repetition(3),
+ * bit8 can_claim_threefold, bit9 fivefold, bit10 seventyfive ; result = game_result(board) */
+int m0_rules_probe(const m0_selfplay_cfg* cfg, const char* fen, const char* const* ucis, int n, int* flags, float* result);
 
 #ifdef __cplusplus
 }

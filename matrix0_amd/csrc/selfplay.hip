@@ -1,0 +1,696 @@
+// Host engine: drives the device trees and the network, plays the games.
+// Mirrors the per-game loop of selfplay_worker (azchess/selfplay/internal.py:326-679) for many
+// concurrent games: opening plies, draw adjudication, temperature, MCTS.run bookkeeping
+// (mcts.py:318-512), move sampling, resign logic, result and record assembly.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <chrono>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/m0_engine.h"
+#include "capi_common.h"
+#include "chess_core.h"
+#include "host_rules.h"
+#include "net.h"
+#include "tree.h"
+
+using namespace m0;
+
+namespace {
+
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct GameRecordOwner {
+    std::vector<float> s, pi, z, search_values;
+    std::vector<uint8_t> legal_mask;
+    std::vector<uint16_t> played;
+};
+
+struct HostGame {
+    bool in_use = false;
+    int game_index = 0;
+    Pos pos;
+    RepWindow win;
+    std::vector<Move> history;            // all moves incl. opening plies
+    // records
+    std::vector<float> states, pis, search_values;
+    std::vector<int8_t> turns;
+    std::vector<uint8_t> masks;
+    std::vector<int> sims_used;
+    int nstates = 0;
+    double entropy_sum = 0.0;
+    int entropy_count = 0;
+    ResignState resign;
+    HStream rng;                          // PURPOSE_GAME stream: opening plies, playout cap, move sampling
+    double t0 = 0.0;
+    int cur_sims = 0;
+};
+
+}  // namespace
+
+struct m0_selfplay {
+    m0_selfplay_cfg cfg;
+    TreeCfg tc;
+    m0_net* nethandle = nullptr;
+    Net* net = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int G = 0, L = 0, cap = 0, rows_max = 0;
+    TreeDev d;
+    std::vector<void*> allocs;
+    std::vector<GameDev> hg;
+    std::vector<HostGame> games;
+    std::vector<RootResult> hres;
+    float* logits_dev = nullptr;
+    float* values_dev = nullptr;
+    float* ssl_dev = nullptr;
+    int* ids_dev = nullptr;
+    int* slots_dev = nullptr;
+    std::deque<GameRecordOwner*> done_records;
+    std::deque<m0_game_record> done_meta;
+    m0_selfplay_stats stats;
+    int next_game = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::mutex mu;
+    std::vector<Sample> hsamples;
+    int last_rows = 0;
+};
+
+namespace {
+
+template <typename T>
+T* dalloc(m0_selfplay* sp, size_t count) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, bytes);
+    sp->allocs.push_back(p);
+    return (T*)p;
+}
+
+void fill_tree_cfg(const m0_selfplay_cfg& c, TreeCfg& t) {
+    t.fpu_reduction = c.fpu_reduction; t.draw_penalty = c.draw_penalty; t.virtual_loss = c.virtual_loss;
+    t.selection_jitter = c.selection_jitter; t.cpuct = c.cpuct; t.cpuct_start = c.cpuct_start; t.cpuct_end = c.cpuct_end;
+    t.cpuct_plies = c.cpuct_plies; t.use_c_base = c.use_c_base; t.cpuct_c_base = c.cpuct_c_base; t.cpuct_c_init = c.cpuct_c_init;
+    t.dirichlet_alpha = c.dirichlet_alpha; t.dirichlet_frac = c.dirichlet_frac; t.legal_softmax = c.legal_softmax;
+    t.enable_entropy_noise = c.enable_entropy_noise; t.no_instant_backtrack = c.no_instant_backtrack;
+    t.virtual_loss_active = c.virtual_loss_active; t.leaves_per_step = c.inference_batch_size;
+}
+
+void seed_game_dev(GameDev& g, uint64_t base, int uid) {
+    g.seed_jitter = derive_seed(base, uid, PURPOSE_JITTER);
+    g.seed_noise = derive_seed(base, uid, PURPOSE_NOISE);
+    g.seed_dir = derive_seed(base, uid, PURPOSE_DIRICHLET);
+    g.ctr_jitter = g.ctr_noise = g.ctr_dir = 0;
+}
+
+int sync_games_d2h(m0_selfplay* sp) {
+    if (hipMemcpyAsync(sp->hg.data(), sp->d.games, sizeof(GameDev) * sp->G, hipMemcpyDeviceToHost, sp->stream) != hipSuccess) return -1;
+    return hipStreamSynchronize(sp->stream) == hipSuccess ? 0 : -1;
+}
+int sync_games_h2d(m0_selfplay* sp) {
+    return hipMemcpyAsync(sp->d.games, sp->hg.data(), sizeof(GameDev) * sp->G, hipMemcpyHostToDevice, sp->stream) == hipSuccess ? 0 : -1;
+}
+void push_hist(m0_selfplay* sp, int slot, const RepWindow& w) {
+    int n = (int)w.keys.size();
+    const uint64_t* src = w.keys.data();
+    if (n > M0_HIST_CAP) { src += n - M0_HIST_CAP; n = M0_HIST_CAP; }
+    sp->hg[slot].hist_len = n;
+    if (n > 0) (void)hipMemcpyAsync(sp->d.hist + (size_t)slot * M0_HIST_CAP, src, (size_t)n * 8, hipMemcpyHostToDevice, sp->stream);
+}
+
+// configure a search on slot for the host position (MCTS.run prologue, mcts.py:342-396)
+void arm_search(m0_selfplay* sp, int slot, const Pos& pos, const RepWindow& win, int sims, bool dirichlet, bool fresh) {
+    GameDev& g = sp->hg[slot];
+    g.root_pos = pos;
+    g.active = 1; g.sims_done = 0; g.sims_target = sims;
+    g.need_dirichlet = dirichlet ? 1 : 0;
+    g.root_q_from_v = 0;
+    g.root_fresh = fresh ? 1 : 0;
+    g.flip_root_v = (sp->cfg.value_from_white && pos.turn == BLACK) ? 1 : 0;
+    g.finished = 0; g.nsamples = 0;
+    push_hist(sp, slot, win);
+}
+
+void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool have_z, float z_in);
+void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv_ids, std::vector<int>& adv_slots);
+
+void start_game(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::vector<int>& adv_slots) {
+    HostGame& hgm = sp->games[slot];
+    hgm = HostGame();
+    hgm.in_use = true;
+    hgm.game_index = sp->cfg.first_game_index + sp->next_game++;
+    sp->stats.games_started++;
+    parse_fen("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", hgm.pos);
+    hgm.rng = HStream(derive_seed(sp->cfg.seed, hgm.game_index, PURPOSE_GAME));
+    hgm.t0 = now_ms();
+    seed_game_dev(sp->hg[slot], sp->cfg.seed, hgm.game_index);
+    sp->hg[slot].evals = 0;
+    // opening diversity: uniform random legal plies (internal.py:366-379; random.choice -> injected stream)
+    for (int i = 0; i < sp->cfg.opening_random_plies; ++i) {
+        if (is_game_over(hgm.pos, hgm.win, false)) break;
+        Move mv[M0_MAX_MOVES];
+        int n = gen_legal(hgm.pos, mv);
+        if (n <= 0) break;
+        int k = (int)(hgm.rng.next() * n);
+        if (k >= n) k = n - 1;
+        hgm.win.push(hgm.pos, mv[k]);
+        make_move(hgm.pos, mv[k]);
+        hgm.history.push_back(mv[k]);
+    }
+    begin_move(sp, slot, -1, adv_ids, adv_slots);
+}
+
+// top of the per-ply loop (internal.py:382-408): termination tests, then arm the search
+void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv_ids, std::vector<int>& adv_slots) {
+    HostGame& hgm = sp->games[slot];
+    const m0_selfplay_cfg& c = sp->cfg;
+    DrawCfg dc = draw_cfg_from(c);
+    if (is_game_over(hgm.pos, hgm.win, false) || hgm.nstates >= c.max_game_len ||
+        should_adjudicate_draw(hgm.pos, hgm.win, hgm.history, dc)) {
+        finish_game(sp, slot, false, 0, false, 0.f);
+        return;
+    }
+    int sims = playout_cap(c.num_simulations, c.playout_random_frac, hgm.rng.next());
+    hgm.cur_sims = sims;
+    const bool dir = c.dirichlet_plies < 0 || hgm.nstates < c.dirichlet_plies;
+    arm_search(sp, slot, hgm.pos, hgm.win, sims, dir, child_slot < 0);
+    adv_ids.push_back(slot);
+    adv_slots.push_back(child_slot);
+}
+
+void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool have_z, float z_in) {
+    HostGame& hgm = sp->games[slot];
+    const m0_selfplay_cfg& c = sp->cfg;
+    float z = z_in;
+    if (!have_z) {
+        // internal.py:587-599 computed per game (SURVEY B-8: the reference's stale-z reuse is not reproduced)
+        if (is_game_over(hgm.pos, hgm.win, true)) z = game_result(hgm.pos);
+        else z = hgm.search_values.empty() ? 0.f : hgm.search_values.back();
+    }
+    sp->stats.games_finished++;
+    if (c.record_games && hgm.nstates > 0) {
+        GameRecordOwner* o = new GameRecordOwner();
+        o->s.swap(hgm.states); o->pi.swap(hgm.pis); o->legal_mask.swap(hgm.masks);
+        o->search_values = hgm.search_values;
+        o->z.resize(hgm.nstates);
+        for (int i = 0; i < hgm.nstates; ++i) o->z[i] = z * (float)hgm.turns[i];
+        o->played.assign(hgm.history.begin(), hgm.history.end());
+        m0_game_record r;
+        memset(&r, 0, sizeof(r));
+        r.game_index = hgm.game_index; r.moves = hgm.nstates; r.resigned = resigned ? 1 : 0; r.resigner = resigner;
+        r.draw = z == 0.0f ? 1 : 0; r.total_plies = (int)hgm.history.size(); r.result = z;
+        r.avg_policy_entropy = (float)(hgm.entropy_sum / (double)(hgm.entropy_count > 0 ? hgm.entropy_count : 1));
+        double ss = 0; for (int v : hgm.sims_used) ss += v;
+        r.avg_sims = hgm.sims_used.empty() ? 0.f : (float)(ss / (double)hgm.sims_used.size());
+        r.secs = (now_ms() - hgm.t0) / 1000.0;
+        r.s = o->s.data(); r.pi = o->pi.data(); r.z = o->z.data(); r.legal_mask = o->legal_mask.data();
+        r.search_values = o->search_values.data(); r.played = o->played.data(); r.owner = o;
+        sp->done_meta.push_back(r);
+    }
+    hgm.in_use = false;
+    sp->hg[slot].active = 0;
+}
+
+// MCTS.run epilogue + the rest of the per-ply loop body (mcts.py:431-507, internal.py:408-539)
+void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::vector<int>& adv_slots) {
+    HostGame& hgm = sp->games[slot];
+    const m0_selfplay_cfg& c = sp->cfg;
+    const RootResult& R = sp->hres[slot];
+    const GameDev& g = sp->hg[slot];
+    const int k = R.nchild;
+    long total = 0;
+    int maxv = 0;
+    for (int i = 0; i < k; ++i) { total += R.child_n[i]; if (R.child_n[i] > maxv) maxv = R.child_n[i]; }
+    if (k <= 0 || total <= 0) {        // mcts.py:435-463 raises RuntimeError; the engine drops the game loudly
+        sp->stats.arena_overflows++;
+        finish_game(sp, slot, false, 0, false, 0.f);
+        return;
+    }
+    const double root_q = R.root_n > 0 ? R.root_q : g.root_v;
+    // policy target (mcts.py:828-837)
+    const size_t T = (size_t)hgm.nstates;
+    if (c.record_games) {
+        hgm.pis.resize((T + 1) * 4672, 0.f);
+        float* pi = hgm.pis.data() + T * 4672;
+        for (int i = 0; i < k; ++i) pi[R.child_idx[i]] = (float)((double)R.child_n[i] / (double)total);
+        hgm.states.resize((T + 1) * 19 * 64);
+        encode_planes_f32(hgm.pos, hgm.states.data() + T * 19 * 64);
+        hgm.masks.resize((T + 1) * 4672, 0);
+        uint8_t* mk = hgm.masks.data() + T * 4672;
+        for (int i = 0; i < k; ++i) mk[R.child_idx[i]] = 1;
+    }
+    // entropy of pi (internal.py:430-436)
+    {
+        double ent = 0.0;
+        for (int i = 0; i < k; ++i) {
+            double p = (double)(float)((double)R.child_n[i] / (double)total);
+            if (p < 1e-12) p = 1e-12;
+            ent -= p * log(p);
+        }
+        ent -= (double)(4672 - k) * (1e-12 * log(1e-12));
+        hgm.entropy_sum += ent; hgm.entropy_count++;
+        hgm.resign.recent_entropies.push_back(ent);
+        if ((int)hgm.resign.recent_entropies.size() > c.resign_window) hgm.resign.recent_entropies.erase(hgm.resign.recent_entropies.begin());
+    }
+    // temperature + move choice (internal.py:386-394, 418-427, 690-735)
+    double temp = temperature_for(hgm.pos.fullmove, c.temperature_start, c.temperature_end, c.temperature_moves);
+    if (c.low_visit_threshold > 0 && maxv < c.low_visit_threshold && temp < 0.8) temp = 0.8;
+    std::vector<int32_t> visits(R.child_n, R.child_n + k);
+    const int pick = sample_move_index(visits.data(), k, temp, hgm.rng.next());
+    const Move mv = R.child_mv[pick];
+    hgm.search_values.push_back((float)root_q);
+    hgm.turns.push_back(hgm.pos.turn == WHITE ? 1 : -1);
+    hgm.sims_used.push_back(hgm.cur_sims);
+    hgm.nstates++;
+    sp->stats.plies++;
+    // resign (internal.py:507-536)
+    if (resign_update(hgm.resign, root_q, hgm.nstates, c)) {
+        const bool white = hgm.pos.turn == WHITE;
+        finish_game(sp, slot, true, white ? 1 : 2, true, white ? -1.f : 1.f);
+        return;
+    }
+    hgm.win.push(hgm.pos, mv);
+    make_move(hgm.pos, mv);
+    hgm.history.push_back(mv);
+    begin_move(sp, slot, pick, adv_ids, adv_slots);
+}
+
+int run_select(m0_selfplay* sp, int* rows_out) {
+    if (hipMemsetAsync(sp->d.row_counter, 0, 4, sp->stream) != hipSuccess) return -1;
+    if (launch_select(sp->d, sp->tc, sp->stream) != hipSuccess) return -1;
+    int rows = 0;
+    if (hipMemcpyAsync(&rows, sp->d.row_counter, 4, hipMemcpyDeviceToHost, sp->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(sp->stream) != hipSuccess) return -1;
+    *rows_out = rows;
+    return 0;
+}
+
+int apply_advances(m0_selfplay* sp, std::vector<int>& ids, std::vector<int>& slots) {
+    if (sync_games_h2d(sp) != 0) return -1;
+    if (!ids.empty()) {
+        (void)hipMemcpyAsync(sp->ids_dev, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, sp->stream);
+        (void)hipMemcpyAsync(sp->slots_dev, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, sp->stream);
+        if (launch_advance(sp->d, sp->ids_dev, sp->slots_dev, (int)ids.size(), sp->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(sp->stream) != hipSuccess) return -1;   // ids/slots vectors die with the caller
+    }
+    return 0;
+}
+
+int one_step(m0_selfplay* sp, std::string& err) {
+    const double t0 = now_ms();
+    (void)hipEventRecord(sp->ev0, sp->stream);
+    int rows = 0;
+    if (run_select(sp, &rows) != 0) { err = std::string("select failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
+    (void)hipEventRecord(sp->ev1, sp->stream);
+    if (rows > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
+    if (rows > 0) {
+        if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
+        int rc = sp->net->forward(nullptr, sp->d.x0, rows, sp->logits_dev, sp->values_dev,
+                                  sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr, sp->stream, err);
+        if (rc != M0_OK) return rc;
+    }
+    (void)hipEventRecord(sp->ev2, sp->stream);
+    if (launch_expand(sp->d, sp->tc, sp->stream) != hipSuccess) { err = "expand launch failed"; return M0_ERR_HIP; }
+    (void)hipEventRecord(sp->ev3, sp->stream);
+    if (sync_games_d2h(sp) != 0) { err = std::string("step failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
+    float ms_sel = 0, ms_net = 0, ms_exp = 0;
+    (void)hipEventElapsedTime(&ms_sel, sp->ev0, sp->ev1);
+    (void)hipEventElapsedTime(&ms_net, sp->ev1, sp->ev2);
+    (void)hipEventElapsedTime(&ms_exp, sp->ev2, sp->ev3);
+    sp->stats.ms_net += ms_net; sp->stats.ms_tree += ms_sel + ms_exp;
+    sp->stats.steps++; sp->stats.evals += (uint64_t)rows;
+    const double t1 = now_ms();
+    // host: finished searches -> moves, game ends, restarts
+    bool any = false;
+    int sims_step = 0;
+    for (int s = 0; s < sp->G; ++s) if (sp->hg[s].active) { sims_step += 0; if (sp->hg[s].finished) any = true; }
+    (void)sims_step;
+    std::vector<int> ids, slots;
+    if (any) {
+        (void)hipMemcpy(sp->hres.data(), sp->d.results, sizeof(RootResult) * sp->G, hipMemcpyDeviceToHost);
+        for (int s = 0; s < sp->G; ++s) {
+            if (!(sp->hg[s].active && sp->hg[s].finished)) continue;
+            if (sp->hg[s].overflow) sp->stats.arena_overflows++;
+            sp->stats.sims += (uint64_t)sp->hg[s].sims_done;
+            finish_search(sp, s, ids, slots);
+        }
+        // refill free slots
+        for (int s = 0; s < sp->G; ++s) {
+            if (sp->games[s].in_use) continue;
+            if (sp->cfg.total_games > 0 && sp->next_game >= sp->cfg.total_games) continue;
+            start_game(sp, s, ids, slots);
+        }
+        if (apply_advances(sp, ids, slots) != 0) { err = "advance failed"; return M0_ERR_HIP; }
+    }
+    int act = 0;
+    for (int s = 0; s < sp->G; ++s) act += sp->games[s].in_use ? 1 : 0;
+    sp->stats.active_games = act;
+    const double t2 = now_ms();
+    sp->stats.ms_host += t2 - t1;
+    sp->stats.ms_total += t2 - t0;
+    return M0_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
+    if (!cfg) { m0_set_error("cfg is null"); return nullptr; }
+    if (cfg->concurrent_games <= 0 || cfg->inference_batch_size <= 0 || cfg->num_simulations <= 0) {
+        m0_set_error("concurrent_games, inference_batch_size and num_simulations must be positive");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { m0_set_error("no HIP device available (no CPU fallback)"); return nullptr; }
+    m0_selfplay* sp = new m0_selfplay();
+    sp->cfg = *cfg;
+    fill_tree_cfg(*cfg, sp->tc);
+    sp->nethandle = nh;
+    sp->net = m0_net_impl(nh);
+    sp->device = nh ? m0_net_device(nh) : 0;
+    (void)hipSetDevice(sp->device);
+    if (nh) sp->stream = m0_net_stream(nh);
+    else { (void)hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking); sp->own_stream = true; }
+    sp->G = cfg->concurrent_games;
+    sp->L = cfg->inference_batch_size;
+    // arena: reused subtree + one search of new children (218 max per expansion is far above the ~35 mean)
+    long want = cfg->arena_nodes > 0 ? cfg->arena_nodes : (long)(cfg->num_simulations * 1.3 + 64) * 96;
+    if (want < 4096) want = 4096;
+    sp->cap = (int)want;
+    sp->rows_max = sp->G * sp->L;
+    memset(&sp->stats, 0, sizeof(sp->stats));
+    memset(&sp->d, 0, sizeof(sp->d));
+    const size_t N = (size_t)sp->G * 2 * sp->cap;
+    TreeArrays& t = sp->d.t;
+    t.cap = sp->cap;
+    t.prior = dalloc<double>(sp, N); t.w = dalloc<double>(sp, N); t.q = dalloc<double>(sp, N);
+    t.n = dalloc<int>(sp, N); t.vl = dalloc<int>(sp, N); t.cbase = dalloc<int>(sp, N);
+    t.nch = dalloc<int16_t>(sp, N); t.mv = dalloc<uint16_t>(sp, N); t.midx = dalloc<uint16_t>(sp, N);
+    sp->d.games = dalloc<GameDev>(sp, sp->G);
+    sp->d.samples = dalloc<Sample>(sp, (size_t)sp->G * sp->L);
+    sp->d.paths = dalloc<int>(sp, (size_t)sp->G * sp->L * M0_MAX_DEPTH);
+    sp->d.hist = dalloc<uint64_t>(sp, (size_t)sp->G * M0_HIST_CAP);
+    sp->d.results = dalloc<RootResult>(sp, sp->G);
+    sp->d.row_counter = dalloc<int>(sp, 4);
+    sp->d.x0 = dalloc<_Float16>(sp, (size_t)(sp->rows_max + 4) * 64 * 32);
+    sp->logits_dev = dalloc<float>(sp, (size_t)sp->rows_max * 4672);
+    sp->values_dev = dalloc<float>(sp, (size_t)sp->rows_max + 4);
+    if (cfg->ssl_in_forward && sp->net && sp->net->ssl_channels_total() > 0)
+        sp->ssl_dev = dalloc<float>(sp, (size_t)sp->rows_max * sp->net->ssl_channels_total() * 64);
+    sp->ids_dev = dalloc<int>(sp, sp->G);
+    sp->slots_dev = dalloc<int>(sp, sp->G);
+    sp->d.logits = sp->logits_dev; sp->d.values = sp->values_dev;
+    sp->d.G = sp->G; sp->d.L = sp->L;
+    bool ok = t.prior && t.w && t.q && t.n && t.vl && t.cbase && t.nch && t.mv && t.midx && sp->d.games && sp->d.samples &&
+              sp->d.paths && sp->d.hist && sp->d.results && sp->d.row_counter && sp->d.x0 && sp->logits_dev && sp->values_dev &&
+              sp->ids_dev && sp->slots_dev;
+    if (!ok) {
+        m0_set_error("hipMalloc failed for the search arenas (lower concurrent_games or arena_nodes)");
+        m0_selfplay_destroy(sp);
+        return nullptr;
+    }
+    sp->hg.assign(sp->G, GameDev());
+    for (auto& g : sp->hg) memset(&g, 0, sizeof(GameDev));
+    sp->games.assign(sp->G, HostGame());
+    sp->hres.resize(sp->G);
+    sp->hsamples.resize((size_t)sp->G * sp->L);
+    (void)hipEventCreate(&sp->ev0); (void)hipEventCreate(&sp->ev1); (void)hipEventCreate(&sp->ev2); (void)hipEventCreate(&sp->ev3);
+    if (sp->net) {
+        std::string err;
+        if (sp->net->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
+    }
+    (void)hipStreamSynchronize(sp->stream);
+    return sp;
+}
+
+void m0_selfplay_destroy(m0_selfplay* sp) {
+    if (!sp) return;
+    (void)hipSetDevice(sp->device);
+    if (sp->stream) (void)hipStreamSynchronize(sp->stream);
+    for (void* p : sp->allocs) (void)hipFree(p);
+    for (auto& r : sp->done_meta) delete (GameRecordOwner*)r.owner;
+    if (sp->ev0) { (void)hipEventDestroy(sp->ev0); (void)hipEventDestroy(sp->ev1); (void)hipEventDestroy(sp->ev2); (void)hipEventDestroy(sp->ev3); }
+    if (sp->own_stream && sp->stream) (void)hipStreamDestroy(sp->stream);
+    delete sp;
+}
+
+int m0_selfplay_step(m0_selfplay* sp, int steps) {
+    if (!sp) { m0_set_error("sp is null"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    std::string err;
+    // lazily start the first games
+    if (sp->stats.games_started == 0) {
+        std::vector<int> ids, slots;
+        if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+        for (int s = 0; s < sp->G; ++s) {
+            if (sp->cfg.total_games > 0 && sp->next_game >= sp->cfg.total_games) break;
+            start_game(sp, s, ids, slots);
+        }
+        if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
+    }
+    for (int i = 0; i < steps; ++i) {
+        if (sp->stats.active_games == 0 && sp->stats.steps > 0) break;
+        int rc = one_step(sp, err);
+        if (rc != M0_OK) { m0_set_error(err); return rc; }
+    }
+    return M0_OK;
+}
+
+int m0_selfplay_stats_get(m0_selfplay* sp, m0_selfplay_stats* out) {
+    if (!sp || !out) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    *out = sp->stats;
+    return M0_OK;
+}
+
+int m0_selfplay_poll(m0_selfplay* sp, m0_game_record* out) {
+    if (!sp || !out) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp->done_meta.empty()) return 0;
+    *out = sp->done_meta.front();
+    sp->done_meta.pop_front();
+    return 1;
+}
+
+void m0_game_record_free(m0_game_record* rec) {
+    if (rec && rec->owner) { delete (GameRecordOwner*)rec->owner; rec->owner = nullptr; }
+}
+
+int m0_selfplay_running(m0_selfplay* sp) {
+    if (!sp) return 0;
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp->stats.games_started == 0) return 1;
+    if (sp->stats.active_games > 0) return 1;
+    return (sp->cfg.total_games <= 0 || sp->next_game < sp->cfg.total_games) ? 1 : 0;
+}
+
+// ---------------- split-step search ----------------
+int m0_search_begin(m0_selfplay* sp, int g, const char* fen, int sims, int dirichlet, int game_uid) {
+    if (!sp || !fen || g < 0 || g >= sp->G || sims <= 0) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    Pos p;
+    if (parse_fen(fen, p) != 0) { m0_set_error("bad FEN"); return M0_ERR_INVALID; }
+    if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+    HostGame& hgm = sp->games[g];
+    hgm = HostGame();
+    hgm.in_use = true; hgm.pos = p; hgm.game_index = game_uid;
+    seed_game_dev(sp->hg[g], sp->cfg.seed, game_uid);
+    sp->hg[g].evals = 0;
+    arm_search(sp, g, p, hgm.win, sims, dirichlet != 0, true);
+    std::vector<int> ids{g}, slots{-1};
+    if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
+    return M0_OK;
+}
+
+int m0_search_select(m0_selfplay* sp, int* rows, float* planes, int max_rows) {
+    if (!sp || !rows) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    int r = 0;
+    if (run_select(sp, &r) != 0) { m0_set_error(std::string("select failed: ") + hipGetErrorString(hipGetLastError())); return M0_ERR_HIP; }
+    *rows = r;
+    sp->last_rows = r;
+    if (planes && r > 0) {
+        if (r > max_rows) { m0_set_error("planes buffer too small"); return M0_ERR_INVALID; }
+        if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * sp->L, hipMemcpyDeviceToHost);
+        for (int g = 0; g < sp->G; ++g) {
+            if (!sp->hg[g].active) continue;
+            for (int s = 0; s < sp->hg[g].nsamples; ++s) {
+                const Sample& smp = sp->hsamples[(size_t)g * sp->L + s];
+                if ((smp.kind == 1 || smp.kind == 2) && smp.row >= 0 && smp.row < r)
+                    encode_planes_f32(smp.pos, planes + (size_t)smp.row * 19 * 64);
+            }
+        }
+    }
+    return M0_OK;
+}
+
+int m0_search_expand(m0_selfplay* sp, const float* logits, const float* values, int rows) {
+    if (!sp) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    if (rows != sp->last_rows || rows > sp->rows_max) { m0_set_error("rows does not match the last select"); return M0_ERR_INVALID; }
+    if (rows > 0) {
+        if (!logits || !values) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+        (void)hipMemcpyAsync(sp->logits_dev, logits, (size_t)rows * 4672 * 4, hipMemcpyHostToDevice, sp->stream);
+        (void)hipMemcpyAsync(sp->values_dev, values, (size_t)rows * 4, hipMemcpyHostToDevice, sp->stream);
+    }
+    if (launch_expand(sp->d, sp->tc, sp->stream) != hipSuccess) { m0_set_error("expand launch failed"); return M0_ERR_HIP; }
+    if (sync_games_d2h(sp) != 0) { m0_set_error(std::string("expand failed: ") + hipGetErrorString(hipGetLastError())); return M0_ERR_HIP; }
+    sp->stats.evals += (uint64_t)rows;
+    return M0_OK;
+}
+
+int m0_search_result(m0_selfplay* sp, int g, int* nchild, int32_t* child_n, uint16_t* child_mv, int32_t* child_idx,
+                     double* child_prior, double* child_q, double* root_q, int* root_n, int* finished) {
+    if (!sp || g < 0 || g >= sp->G) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    if (finished) *finished = sp->hg[g].finished;
+    if (!sp->hg[g].finished) { if (nchild) *nchild = 0; return M0_OK; }
+    (void)hipMemcpy(&sp->hres[g], sp->d.results + g, sizeof(RootResult), hipMemcpyDeviceToHost);
+    const RootResult& R = sp->hres[g];
+    if (nchild) *nchild = R.nchild;
+    for (int i = 0; i < R.nchild; ++i) {
+        if (child_n) child_n[i] = R.child_n[i];
+        if (child_mv) child_mv[i] = R.child_mv[i];
+        if (child_idx) child_idx[i] = R.child_idx[i];
+        if (child_prior) child_prior[i] = R.child_prior[i];
+        if (child_q) child_q[i] = R.child_q[i];
+    }
+    if (root_q) *root_q = R.root_n > 0 ? R.root_q : sp->hg[g].root_v;
+    if (root_n) *root_n = R.root_n;
+    return M0_OK;
+}
+
+int m0_search_advance(m0_selfplay* sp, int g, int slot, int sims, int dirichlet) {
+    if (!sp || g < 0 || g >= sp->G || sims <= 0) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    // refresh the mirror first: an earlier advance changed root/next/arena on the device only
+    if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+    if (!sp->hg[g].finished) { m0_set_error("search not finished"); return M0_ERR_STATE; }
+    (void)hipMemcpy(&sp->hres[g], sp->d.results + g, sizeof(RootResult), hipMemcpyDeviceToHost);
+    const RootResult& R = sp->hres[g];
+    if (slot < 0 || slot >= R.nchild) { m0_set_error("child slot out of range"); return M0_ERR_INVALID; }
+    HostGame& hgm = sp->games[g];
+    const Move mv = R.child_mv[slot];
+    hgm.win.push(hgm.pos, mv);
+    make_move(hgm.pos, mv);
+    hgm.history.push_back(mv);
+    arm_search(sp, g, hgm.pos, hgm.win, sims, dirichlet != 0, false);
+    std::vector<int> ids{g}, slots{slot};
+    if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
+    return M0_OK;
+}
+
+// ---------------- encoding.py on the device ----------------
+int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes, uint8_t* mask, int32_t* nlegal,
+                   uint16_t* moves, int32_t* idx) {
+    if (!fens || n <= 0) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { m0_set_error("no HIP device available (no CPU fallback)"); return M0_ERR_HIP; }
+    if (hipSetDevice(hip_device) != hipSuccess) { m0_set_error("hipSetDevice failed"); return M0_ERR_HIP; }
+    std::vector<Pos> hp(n);
+    for (int i = 0; i < n; ++i)
+        if (!fens[i] || parse_fen(fens[i], hp[i]) != 0) { m0_set_error(std::string("bad FEN at index ") + std::to_string(i)); return M0_ERR_INVALID; }
+    Pos* dp = nullptr; float* dpl = nullptr; uint8_t* dm = nullptr; int32_t* dn = nullptr; uint16_t* dmv = nullptr; int32_t* di = nullptr;
+    int rc = M0_OK;
+    auto fail = [&](const char* what) { m0_set_error(what); rc = M0_ERR_HIP; };
+    if (hipMalloc((void**)&dp, sizeof(Pos) * n) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK && planes && hipMalloc((void**)&dpl, (size_t)n * 19 * 64 * 4) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK && mask && hipMalloc((void**)&dm, (size_t)n * 4672) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK && nlegal && hipMalloc((void**)&dn, (size_t)n * 4) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK && moves && hipMalloc((void**)&dmv, (size_t)n * M0_MAX_MOVES * 2) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK && idx && hipMalloc((void**)&di, (size_t)n * M0_MAX_MOVES * 4) != hipSuccess) fail("hipMalloc failed");
+    if (rc == M0_OK) {
+        (void)hipMemcpy(dp, hp.data(), sizeof(Pos) * n, hipMemcpyHostToDevice);
+        if (launch_encode_positions(dp, n, dpl, nullptr, dm, dn, dmv, di, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            fail("encode kernel failed");
+    }
+    if (rc == M0_OK) {
+        if (planes) (void)hipMemcpy(planes, dpl, (size_t)n * 19 * 64 * 4, hipMemcpyDeviceToHost);
+        if (mask) (void)hipMemcpy(mask, dm, (size_t)n * 4672, hipMemcpyDeviceToHost);
+        if (nlegal) (void)hipMemcpy(nlegal, dn, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (moves) (void)hipMemcpy(moves, dmv, (size_t)n * M0_MAX_MOVES * 2, hipMemcpyDeviceToHost);
+        if (idx) (void)hipMemcpy(idx, di, (size_t)n * M0_MAX_MOVES * 4, hipMemcpyDeviceToHost);
+    }
+    if (dp) (void)hipFree(dp); if (dpl) (void)hipFree(dpl); if (dm) (void)hipFree(dm);
+    if (dn) (void)hipFree(dn); if (dmv) (void)hipFree(dmv); if (di) (void)hipFree(di);
+    return rc;
+}
+
+int m0_move_to_index_fen(int hip_device, const char* fen, const char* uci, int32_t* out) {
+    if (!fen || !uci || !out) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    const Move want = parse_uci(uci);
+    if (want == 0xFFFF) { m0_set_error(std::string("Illegal move: ") + uci); return M0_ERR_INVALID; }
+    std::vector<uint16_t> mv(M0_MAX_MOVES);
+    std::vector<int32_t> id(M0_MAX_MOVES);
+    int32_t n = 0;
+    const char* fens[1] = {fen};
+    int rc = m0_encode_fens(hip_device, fens, 1, nullptr, nullptr, &n, mv.data(), id.data());
+    if (rc != M0_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        if (mv[i] == want) { *out = id[i]; return M0_OK; }
+    m0_set_error(std::string("Illegal move: ") + uci);     // encoding.py:120-121 raises ValueError
+    return M0_ERR_INVALID;
+}
+
+// ---------------- host decision functions ----------------
+int m0_sample_move_index(const int32_t* visits, int n, double temperature, double u) {
+    if (!visits || n <= 0) return -1;
+    return sample_move_index(visits, n, temperature, u);
+}
+int m0_playout_cap(int sims, double frac, double u) { return playout_cap(sims, frac, u); }
+double m0_temperature_for(int fullmove_number, double t_start, double t_end, int t_moves) {
+    return temperature_for(fullmove_number, t_start, t_end, t_moves);
+}
+int m0_rules_probe(const m0_selfplay_cfg* cfg, const char* fen, const char* const* ucis, int n, int* flags, float* result) {
+    if (!cfg || !fen || !flags) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    Pos p;
+    if (parse_fen(fen, p) != 0) { m0_set_error("bad FEN"); return M0_ERR_INVALID; }
+    RepWindow w;
+    std::vector<Move> hist;
+    for (int i = 0; i < n; ++i) {
+        Move m = parse_uci(ucis[i]);
+        Move mv[M0_MAX_MOVES];
+        int k = gen_legal(p, mv);
+        bool ok = false;
+        for (int j = 0; j < k; ++j) if (mv[j] == m) ok = true;
+        if (!ok) { m0_set_error(std::string("Illegal move: ") + ucis[i]); return M0_ERR_INVALID; }
+        w.push(p, m);
+        make_move(p, m);
+        hist.push_back(m);
+    }
+    DrawCfg dc = draw_cfg_from(*cfg);
+    int f = 0;
+    if (is_game_over(p, w, false)) f |= 1;
+    if (is_game_over(p, w, true)) f |= 2;
+    if (should_adjudicate_draw(p, w, hist, dc)) f |= 4;
+    const bool anyl = any_legal(p), chk = in_check(p);
+    if (!anyl && chk) f |= 8;
+    if (!anyl && !chk) f |= 16;
+    if (is_insufficient(p)) f |= 32;
+    if (can_claim_fifty(p)) f |= 64;
+    if (w.is_repetition(p, 3)) f |= 128;
+    if (w.can_claim_threefold(p)) f |= 256;
+    if (w.is_repetition(p, 5)) f |= 512;
+    if (p.halfmove >= 150 && anyl) f |= 1024;
+    *flags = f;
+    if (result) *result = game_result(p);
+    return M0_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// Device-resident search trees: one arena pair per concurrent game, SoA node arrays so a
+// node's children (contiguous block) load coalesced, one child per lane.
+// Mirrors azchess/mcts.py Node (120-133) / _select (851-925) / _expand (135-225) /
+// _backpropagate (946-953) / _add_dirichlet (955-992).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "chess_core.h"
+
+#define M0_MAX_DEPTH 256      // path length cap (nodes)
+#define M0_HIST_CAP 192       // reversible-move history window (<= 150 by the 75-move rule)
+#define M0_MAX_CHILDREN 256
+
+struct TreeCfg {              // MCTSConfig fields the kernels read (mcts.py:61-107)
+    double fpu_reduction;
+    double draw_penalty;
+    double virtual_loss;
+    double selection_jitter;
+    double cpuct;
+    double cpuct_start, cpuct_end;
+    int cpuct_plies;          // <=0: constant cpuct
+    int use_c_base;
+    double cpuct_c_base, cpuct_c_init;
+    double dirichlet_alpha, dirichlet_frac;
+    int legal_softmax;
+    int enable_entropy_noise;
+    int no_instant_backtrack;
+    int virtual_loss_active;  // 1: apply the in-flight penalty as written (mcts.py:889-890, 922-923)
+    int leaves_per_step;      // L = inference_batch_size per tree
+};
+
+// Per-game control block (host writes between steps, kernels update counters).
+struct GameDev {
+    m0::Pos root_pos;
+    int root;                 // node index of the root (arena-relative)
+    int next;                 // bump allocator
+    int arena;                // 0/1: which arena half holds the tree
+    int active;               // searching
+    int sims_done, sims_target;
+    int need_dirichlet;       // apply Dirichlet noise at the next select (run(): mcts.py:374-376)
+    int root_q_from_v;        // expanding a reused-but-unexpanded root sets root.q = v (mcts.py:412-413)
+    int flip_root_v;          // value_from_white && black to move (mcts.py:1182-1188, root eval only)
+    int root_fresh;           // root is a brand-new Node (mcts.py:344-358) rather than a reused child
+    int hist_len;
+    int nsamples;             // samples produced by the last select
+    int overflow;             // arena exhausted at least once
+    int finished;             // sims_done >= sims_target after the last expand
+    int root_n;
+    double root_q;
+    double root_v;            // network value of the last root evaluation
+    uint64_t seed_jitter, seed_noise, seed_dir;
+    uint64_t ctr_jitter, ctr_noise, ctr_dir;
+    uint64_t evals;           // network evaluations consumed by this game (counted by the engine)
+};
+
+struct Sample {
+    m0::Pos pos;              // leaf position
+    int kind;                 // 0 none, 1 eval+backup, 2 root init (expand only), 3 terminal (already backed up)
+    int leaf;
+    int depth;                // path has depth+1 nodes
+    int row;                  // network batch row
+};
+
+struct TreeArrays {           // each [G][2*cap]
+    double* prior;
+    double* w;
+    double* q;
+    int* n;
+    int* vl;
+    int* cbase;
+    int16_t* nch;             // -1 not expanded
+    uint16_t* mv;
+    uint16_t* midx;
+    int cap;                  // nodes per arena half
+};
+
+struct RootResult {           // written when a search finishes
+    int nchild;
+    int root_n;
+    double root_q;
+    int child_node[M0_MAX_CHILDREN];
+    int child_n[M0_MAX_CHILDREN];
+    uint16_t child_mv[M0_MAX_CHILDREN];
+    uint16_t child_idx[M0_MAX_CHILDREN];
+    double child_prior[M0_MAX_CHILDREN];
+    double child_q[M0_MAX_CHILDREN];
+};
+
+struct TreeDev {
+    TreeArrays t;
+    GameDev* games;           // [G]
+    Sample* samples;          // [G][L]
+    int* paths;               // [G][L][M0_MAX_DEPTH]
+    uint64_t* hist;           // [G][M0_HIST_CAP]
+    RootResult* results;      // [G]
+    int* row_counter;         // [1]
+    _Float16* x0;             // network input NHWC [rows][64][32]
+    const float* logits;      // [rows][4672]
+    const float* values;      // [rows]
+    int G;
+    int L;
+};
+
+hipError_t launch_select(const TreeDev& d, const TreeCfg& c, hipStream_t st);
+hipError_t launch_expand(const TreeDev& d, const TreeCfg& c, hipStream_t st);
+hipError_t launch_advance(const TreeDev& d, const int* game_ids_dev, const int* child_slots_dev, int count, hipStream_t st);
+
+// test hooks: position-wise encode / legal move / index kernels (encoding.py on device)
+struct PosQuery {
+    m0::Pos pos;
+};
+hipError_t launch_encode_positions(const m0::Pos* pos_dev, int n, float* planes_f32_dev /*[n][19][64]*/,
+                                   _Float16* nhwc_dev /*[n][64][32] or null*/, uint8_t* mask_dev /*[n][4672]*/,
+                                   int32_t* nlegal_dev, uint16_t* moves_dev /*[n][256]*/, int32_t* idx_dev /*[n][256]*/,
+                                   hipStream_t st);

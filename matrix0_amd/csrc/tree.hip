@@ -1,0 +1,559 @@
+// Tree-search kernels: one wavefront per game tree.
+//   select_kernel   L descents per game and step: children scored one per lane from coalesced SoA
+//                   loads (PUCT + FPU + virtual loss + jitter in fp64, mcts.py:851-925), wave
+//                   arg-max with first-max tie-break, leaf board by make_move, terminal test,
+//                   immediate terminal backup, 19-plane encode written straight into the network
+//                   input (lane = square).
+//   expand_kernel   after the network: legal moves, policy indices, legal-only softmax, entropy
+//                   noise, renormalise (mcts.py:135-225), child block allocation, backup
+//                   (mcts.py:946-953), virtual-loss release, root result extraction.
+//   advance_kernel  re-root on the played move and compact the kept subtree into the other arena.
+//   encode_positions_kernel  position-wise encoding.py functions (parity tests / boundary helpers).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "tree.h"
+
+using namespace m0;
+
+#define GOLDEN64 0x9E3779B97F4A7C15ull
+
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t k) {
+    return (double)(mix64(seed + (k + 1) * GOLDEN64) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double normal_at(uint64_t seed, uint64_t k) {   // consumes uniforms k, k+1
+    double u1 = u01(seed, k), u2 = u01(seed, k + 1);
+    if (u1 < 1e-300) u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * 3.141592653589793 * u2);
+}
+__device__ double gamma_draw(uint64_t seed, uint64_t& ctr, double a) {     // Marsaglia-Tsang
+    double boost = 1.0;
+    if (a < 1.0) {
+        double u = u01(seed, ctr++);
+        boost = pow(u, 1.0 / a);
+        a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 1000; ++it) {
+        double x = normal_at(seed, ctr); ctr += 2;
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = u01(seed, ctr++);
+        if (u < 1e-300) u = 1e-300;
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+    }
+    return d * boost;
+}
+
+__device__ __forceinline__ double cpuct_at(const TreeCfg& c, int ply) {    // mcts.py:927-944
+    if (c.use_c_base) {
+        double N = fmax(1.0, (double)(ply + 1));
+        return c.cpuct_c_init + log((N + c.cpuct_c_base) / c.cpuct_c_base);
+    }
+    if (c.cpuct_plies <= 0) return c.cpuct;
+    int p = ply < 0 ? 0 : (ply > c.cpuct_plies ? c.cpuct_plies : ply);
+    double t = (double)p / (double)c.cpuct_plies;
+    return c.cpuct_start + (c.cpuct_end - c.cpuct_start) * t;
+}
+
+struct Arena {
+    double* prior; double* w; double* q; int* n; int* vl; int* cbase; int16_t* nch; uint16_t* mv; uint16_t* midx;
+};
+__device__ __forceinline__ Arena arena_of(const TreeArrays& t, int g, int half) {
+    size_t b = ((size_t)g * 2 + half) * (size_t)t.cap;
+    Arena a;
+    a.prior = t.prior + b; a.w = t.w + b; a.q = t.q + b; a.n = t.n + b; a.vl = t.vl + b;
+    a.cbase = t.cbase + b; a.nch = t.nch + b; a.mv = t.mv + b; a.midx = t.midx + b;
+    return a;
+}
+
+// lane = tensor square n (row-major, row 0 = rank 8): 32 fp16 channels (19 used)
+__device__ void encode_nhwc(const Pos& p, _Float16* dst /*[64][32]*/, int lane) {
+    const int s = (7 - (lane >> 3)) * 8 + (lane & 7);
+    float c7[7];
+    plane_consts(p, c7);
+    const int pl = piece_plane(p, s);
+    __attribute__((aligned(16))) _Float16 h[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) h[i] = (_Float16)0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) h[i] = (_Float16)(pl == i ? 1.f : 0.f);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) h[12 + i] = (_Float16)c7[i];
+    uint4* o = reinterpret_cast<uint4*>(dst + lane * 32);
+    const uint4* hv = reinterpret_cast<const uint4*>(h);
+    o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
+}
+
+__device__ void backprop(const Arena& A, const int* path, int depth, double value) {   // lane-0 caller
+    double v = fmax(-1.0, fmin(1.0, value));
+    for (int d = depth; d >= 0; --d) {
+        const int nd = path[d];
+        const int nn = A.n[nd] + 1;
+        const double ww = A.w[nd] + v;
+        A.n[nd] = nn; A.w[nd] = ww; A.q[nd] = ww / (double)nn;
+        v = -v;
+    }
+}
+
+__device__ void apply_dirichlet(const Arena& A, int root, GameDev* gd, const TreeCfg& c, double* sg, int lane) {
+    const int k = A.nch[root];
+    if (k <= 0 || c.dirichlet_frac <= 0.0) return;
+    const int cb = A.cbase[root];
+    uint64_t ctr = gd->ctr_dir;
+    double sum = 0.0;
+    for (int i = 0; i < k; ++i) {                 // sequential draws, uniform across lanes
+        double gmm = gamma_draw(gd->seed_dir, ctr, c.dirichlet_alpha);
+        if (lane == 0) sg[i] = gmm;
+        sum += gmm;
+    }
+    __syncthreads();
+    for (int i = lane; i < k; i += 64) {
+        double nv = A.prior[cb + i] * (1.0 - c.dirichlet_frac) + (sg[i] / sum) * c.dirichlet_frac;
+        A.prior[cb + i] = fmax(1e-8, fmin(1.0 - 1e-8, nv));
+    }
+    if (lane == 0) gd->ctr_dir = ctr;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
+    __shared__ uint64_t pkey[M0_MAX_DEPTH];
+    __shared__ uint8_t pirr[M0_MAX_DEPTH];
+    __shared__ Move smoves[M0_MAX_MOVES];
+    __shared__ double sg[M0_MAX_CHILDREN];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    GameDev* gd = &d.games[g];
+    if (!gd->active) { if (lane == 0) gd->nsamples = 0; return; }
+    const Arena A = arena_of(d.t, g, gd->arena);
+    const int root = gd->root;
+    Sample* S = d.samples + (size_t)g * d.L;
+    int* P = d.paths + (size_t)g * d.L * M0_MAX_DEPTH;
+
+    if (A.nch[root] < 0) {                       // root not expanded: one network evaluation, no simulation
+        if (lane == 0 && !gd->root_fresh) {
+            // reused but never expanded child: run() applies Dirichlet BEFORE expanding it (a no-op on a
+            // childless node, mcts.py:374-376 vs 398-413) and then sets root.q = v
+            gd->need_dirichlet = 0;
+            gd->root_q_from_v = 1;
+        }
+        int row = 0;
+        if (lane == 0) row = atomicAdd(d.row_counter, 1);
+        row = __shfl(row, 0);
+        const Pos rp = gd->root_pos;
+        if (lane == 0) {
+            Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row;
+            S[0] = s; P[0] = root; gd->nsamples = 1;
+        }
+        encode_nhwc(rp, d.x0 + (size_t)row * 64 * 32, lane);
+        return;
+    }
+    if (gd->need_dirichlet) {
+        apply_dirichlet(A, root, gd, c, sg, lane);
+        if (lane == 0) gd->need_dirichlet = 0;
+    }
+    int nleaf = gd->sims_target - gd->sims_done;
+    if (nleaf > d.L) nleaf = d.L;
+    if (nleaf < 0) nleaf = 0;
+    uint64_t ctrj = gd->ctr_jitter;
+    const uint64_t seedj = gd->seed_jitter;
+    const double jit = c.selection_jitter > 0.0 ? c.selection_jitter : 0.001;
+    const int hist_len = gd->hist_len;
+    const uint64_t* H = d.hist + (size_t)g * M0_HIST_CAP;
+
+    for (int s = 0; s < nleaf; ++s) {
+        Pos pos = gd->root_pos;
+        int* path = P + (size_t)s * M0_MAX_DEPTH;
+        int node = root, depth = 0;
+        int prev_from = -1, prev_to = -1;
+        if (lane == 0) path[0] = root;
+        while (true) {
+            const int nc = A.nch[node];
+            if (nc <= 0 || depth >= M0_MAX_DEPTH - 1) break;
+            const int cb = A.cbase[node];
+            const double nq = A.q[node];
+            const int nn = A.n[node];
+            const double sq = sqrt((double)(nn > 1 ? nn : 1));
+            const double eff = cpuct_at(c, depth);
+            double best = -1e9;
+            int bi = -1;
+            for (int i = lane; i < nc; i += 64) {
+                const int ci = cb + i;
+                const int cn = A.n[ci];
+                const double qq = cn == 0 ? nq - c.fpu_reduction : A.q[ci];
+                const double u = eff * A.prior[ci] * (sq / (1.0 + (double)cn));
+                double sc = qq + u;
+                if (c.no_instant_backtrack && depth >= 1) {
+                    const Move m = A.mv[ci];
+                    if (mv_from(m) == prev_to && mv_to(m) == prev_from) sc -= 0.01;
+                }
+                if (c.virtual_loss_active && c.virtual_loss > 0.0) sc -= (double)A.vl[ci] * c.virtual_loss;
+                sc += (u01(seedj, ctrj + (uint64_t)i) - 0.5) * jit;
+                if (sc > best) { best = sc; bi = i; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(bi, off);
+                if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+            }
+            ctrj += (uint64_t)nc;
+            if (bi < 0) bi = 0;
+            const int child = cb + bi;
+            const Move m = A.mv[child];
+            const uint64_t k = tkey(pos);
+            const bool irr = irreversible(pos, m);
+            if (lane == 0) { pkey[depth] = k; pirr[depth] = irr ? 1 : 0; }
+            make_move(pos, m);
+            if (lane == 0 && c.virtual_loss_active) A.vl[child] += 1;
+            prev_from = mv_from(m); prev_to = mv_to(m);
+            node = child; ++depth;
+            if (lane == 0) path[depth] = node;
+            __syncthreads();
+        }
+        // leaf: is_game_over() (checkmate, insufficient, stalemate, 75-move, fivefold) -> _terminal_value
+        const int nlegal = gen_legal(pos, smoves);
+        const bool chk = in_check(pos);
+        bool term = false;
+        double tv = 0.0;
+        if (nlegal == 0) { term = true; tv = chk ? -1.0 : c.draw_penalty; }
+        else if (is_insufficient(pos)) { term = true; tv = c.draw_penalty; }
+        else if (pos.halfmove >= 150) { term = true; tv = c.draw_penalty; }
+        else {
+            const uint64_t lk = tkey(pos);
+            int cnt = 1;
+            bool broke = false;
+            for (int dd = depth - 1; dd >= 0; --dd) {
+                if (pirr[dd]) { broke = true; break; }
+                if (pkey[dd] == lk) ++cnt;
+            }
+            if (!broke)
+                for (int i = hist_len - 1; i >= 0; --i)
+                    if (H[i] == lk) ++cnt;
+            if (cnt >= 5) { term = true; tv = c.draw_penalty; }
+        }
+        int row = -1;
+        if (!term) {
+            if (lane == 0) row = atomicAdd(d.row_counter, 1);
+            row = __shfl(row, 0);
+            encode_nhwc(pos, d.x0 + (size_t)row * 64 * 32, lane);
+        }
+        if (lane == 0) {
+            Sample smp; smp.pos = pos; smp.kind = term ? 3 : 1; smp.leaf = node; smp.depth = depth; smp.row = row;
+            S[s] = smp;
+            if (term) backprop(A, path, depth, tv);     // mcts.py:747-751: terminal leaves back up immediately
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { gd->ctr_jitter = ctrj; gd->nsamples = nleaf; }
+}
+
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Node._expand (mcts.py:135-225) for one leaf; returns false if the arena is exhausted
+__device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg& c, int leaf, const Pos& pos,
+                            const float* lg, Move* smoves, int lane) {
+    const int n = gen_legal(pos, smoves);
+    __syncthreads();
+    if (n <= 0) return true;
+    // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
+    bool bad = false;
+    for (int j = lane; j < 4672; j += 64) { float x = lg[j]; if (!isfinite(x)) bad = true; }
+    bad = __any(bad);
+    float pr[4];
+    int idx[4];
+    Move mvv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        pr[k] = 0.f; idx[k] = 0; mvv[k] = 0;
+        if (i < n) { mvv[k] = smoves[i]; idx[k] = move_to_index(pos, mvv[k]); }
+    }
+    if (bad) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pr[k] = 1.0f / (float)n;
+    } else {
+        // Softmax numerics: (logit - max) in float32 as torch does, exp/sum/divide in float64, result rounded
+        // to float32.  Within one float32 ulp of the reference's torch.softmax (mcts.py:158-168) and
+        // reproducible bit-for-bit on the host (oracle mode "engine"); entropy in float64.
+        float mx = -3.0e38f;
+        int cnt;                                      // size of the active distribution
+        double ent = 0.0;
+        double fsum = 1.0, fmx = 0.0;                 // full-softmax normaliser (legal_softmax == 0)
+        if (c.legal_softmax) {
+            cnt = n;
+            float l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; l[k] = i < n ? lg[idx[k]] : -3.0e38f; mx = fmaxf(mx, l[k]); }
+            mx = wave_max_f(mx);
+            double e[4], sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; e[k] = i < n ? exp((double)(l[k] - mx)) : 0.0; sum += e[k]; }
+            sum = wave_sum_d(sum);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k;
+                pr[k] = (float)(e[k] / sum);
+                if (i < n) ent -= (double)pr[k] * log((double)pr[k] + 1e-8);
+            }
+        } else {
+            cnt = 4672;
+            for (int j = lane; j < 4672; j += 64) mx = fmaxf(mx, lg[j]);
+            mx = wave_max_f(mx);
+            double sum = 0.0;
+            for (int j = lane; j < 4672; j += 64) sum += exp((double)(lg[j] - mx));
+            sum = wave_sum_d(sum);
+            fsum = sum; fmx = (double)mx;
+            for (int j = lane; j < 4672; j += 64) {
+                const double pj = (double)(float)(exp((double)(lg[j] - mx)) / sum);
+                ent -= pj * log(pj + 1e-8);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; pr[k] = i < n ? (float)(exp((double)(lg[idx[k]] - mx)) / sum) : 0.f; }
+        }
+        ent = wave_sum_d(ent);
+        const double ratio = ent / fmax(1e-9, log((double)(n > 1 ? n : 1)));
+        if (c.enable_entropy_noise && ratio > 0.9) {
+            const uint64_t ctr = gd->ctr_noise;
+            const uint64_t seed = gd->seed_noise;
+            if (c.legal_softmax) {
+                double dd[4], ds = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = lane + 64 * k;
+                    dd[k] = 0.0;
+                    if (i < n) { dd[k] = fmax((double)pr[k] + 0.1 * normal_at(seed, ctr + 2ull * (uint64_t)i), 1e-8); ds += dd[k]; }
+                }
+                ds = wave_sum_d(ds);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pr[k] = (float)(dd[k] / ds);
+            } else {
+                double ds = 0.0;
+                for (int j = lane; j < 4672; j += 64)
+                    ds += fmax((double)(float)(exp((double)(lg[j] - mx)) / fsum) + 0.1 * normal_at(seed, ctr + 2ull * (uint64_t)j), 1e-8);
+                ds = wave_sum_d(ds);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < n) {
+                        const int j = idx[k];
+                        pr[k] = (float)(fmax((double)pr[k] + 0.1 * normal_at(seed, ctr + 2ull * (uint64_t)j), 1e-8) / ds);
+                    }
+                }
+            }
+            if (lane == 0) gd->ctr_noise = ctr + 2ull * (uint64_t)cnt;
+        }
+        // renormalise over the legal moves (mcts.py:205-212): float32 values, float64 sum rounded to float32
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; if (i < n) { if (!(pr[k] >= 0.f) || !isfinite(pr[k])) pr[k] = 0.f; tot += (double)pr[k]; } }
+        tot = wave_sum_d(tot);
+        const float totf = (float)tot;
+        if (totf > 0.f && isfinite(totf)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = pr[k] / totf;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pr[k] = 1.0f / (float)n;
+        }
+    }
+    const int cb = gd->next;
+    if (cb + n > cap) { if (lane == 0) gd->overflow = 1; return false; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const int ci = cb + i;
+            A.prior[ci] = (double)pr[k]; A.w[ci] = 0.0; A.q[ci] = 0.0; A.n[ci] = 0; A.vl[ci] = 0;
+            A.cbase[ci] = -1; A.nch[ci] = -1; A.mv[ci] = mvv[k]; A.midx[ci] = (uint16_t)idx[k];
+        }
+    }
+    if (lane == 0) { A.cbase[leaf] = cb; A.nch[leaf] = (int16_t)n; gd->next = cb + n; }
+    __syncthreads();
+    return true;
+}
+
+__global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
+    __shared__ Move smoves[M0_MAX_MOVES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    GameDev* gd = &d.games[g];
+    if (!gd->active) return;
+    const int ns = gd->nsamples;
+    if (ns <= 0) return;
+    const Arena A = arena_of(d.t, g, gd->arena);
+    const Sample* S = d.samples + (size_t)g * d.L;
+    const int* P = d.paths + (size_t)g * d.L * M0_MAX_DEPTH;
+    int sims = 0;
+    uint64_t evals = 0;
+    for (int s = 0; s < ns; ++s) {
+        const int kind = S[s].kind;
+        const int* path = P + (size_t)s * M0_MAX_DEPTH;
+        if (kind == 1 || kind == 2) {
+            const int leaf = S[s].leaf, depth = S[s].depth, row = S[s].row;
+            const float* lg = d.logits + (size_t)row * 4672;
+            const float v = d.values[row];
+            if (A.nch[leaf] < 0) {
+                const Pos pos = S[s].pos;
+                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, smoves, lane);
+            }
+            ++evals;
+            if (kind == 1) {
+                if (lane == 0) backprop(A, path, depth, (double)v);
+                ++sims;
+            } else {
+                double rv = fmax(-1.0, fmin(1.0, (double)v));
+                if (gd->flip_root_v) rv = -rv;
+                if (lane == 0) {
+                    gd->root_v = rv;
+                    if (gd->root_q_from_v) { A.q[leaf] = rv; gd->root_q_from_v = 0; }
+                }
+            }
+            __syncthreads();
+        } else if (kind == 3) {
+            ++sims;
+        }
+    }
+    // release virtual losses of the whole batch (the reference's inflight dict dies with the batch)
+    if (c.virtual_loss_active && lane == 0) {
+        for (int s = 0; s < ns; ++s) {
+            const int kind = S[s].kind;
+            if (kind == 1 || kind == 3) {
+                const int* path = P + (size_t)s * M0_MAX_DEPTH;
+                for (int dd = 1; dd <= S[s].depth; ++dd) A.vl[path[dd]] -= 1;
+            }
+        }
+    }
+    __syncthreads();
+    const int done = gd->sims_done + sims;
+    const int root = gd->root;
+    const bool fin = (A.nch[root] >= 0 || gd->overflow) && done >= gd->sims_target;
+    if (lane == 0) {
+        gd->sims_done = done;
+        gd->evals += evals;
+        gd->finished = fin ? 1 : 0;
+        gd->root_n = A.n[root];
+        gd->root_q = A.q[root];
+    }
+    if (fin) {
+        RootResult* R = d.results + g;
+        const int k = A.nch[root] > 0 ? A.nch[root] : 0;
+        const int cb = A.cbase[root];
+        for (int i = lane; i < k; i += 64) {
+            R->child_node[i] = cb + i; R->child_n[i] = A.n[cb + i];
+            R->child_mv[i] = A.mv[cb + i]; R->child_idx[i] = A.midx[cb + i];
+            R->child_prior[i] = A.prior[cb + i]; R->child_q[i] = A.q[cb + i];
+        }
+        if (lane == 0) { R->nchild = k; R->root_n = A.n[root]; R->root_q = A.q[root]; }
+    }
+}
+
+// Re-root: child_slot >= 0 keeps that child's subtree (compacted into the other arena half);
+// child_slot < 0 starts a fresh tree.
+__global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_ids, const int* child_slots, int count) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= count) return;
+    const int g = game_ids[j], slot = child_slots[j];
+    GameDev* gd = &d.games[g];
+    if (slot < 0) {
+        const Arena D = arena_of(d.t, g, 0);
+        if (lane == 0) {
+            D.prior[0] = 0.0; D.w[0] = 0.0; D.q[0] = 0.0; D.n[0] = 0; D.vl[0] = 0; D.cbase[0] = -1; D.nch[0] = -1;
+            D.mv[0] = 0; D.midx[0] = 0;
+            gd->arena = 0; gd->root = 0; gd->next = 1; gd->overflow = 0;
+        }
+        return;
+    }
+    const int a = gd->arena;
+    const Arena Sx = arena_of(d.t, g, a), D = arena_of(d.t, g, a ^ 1);
+    const int r = Sx.cbase[gd->root] + slot;
+    if (lane == 0) {
+        D.prior[0] = Sx.prior[r]; D.w[0] = Sx.w[r]; D.q[0] = Sx.q[r]; D.n[0] = Sx.n[r]; D.vl[0] = 0;
+        D.cbase[0] = Sx.cbase[r]; D.nch[0] = Sx.nch[r]; D.mv[0] = Sx.mv[r]; D.midx[0] = Sx.midx[r];
+    }
+    __syncthreads();
+    int head = 0, tail = 1;
+    while (head < tail) {
+        const int lim = tail < head + 64 ? tail : head + 64;
+        const int i = head + lane;
+        const int nc_i = i < lim ? (int)D.nch[i] : -1;
+        const int cb_i = i < lim ? D.cbase[i] : -1;     // still the OLD child base
+        unsigned long long mask = __ballot(nc_i > 0);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int nc = __shfl(nc_i, b), ocb = __shfl(cb_i, b);
+            const int ncb = tail;
+            for (int k = lane; k < nc; k += 64) {
+                const int so = ocb + k, dn = ncb + k;
+                D.prior[dn] = Sx.prior[so]; D.w[dn] = Sx.w[so]; D.q[dn] = Sx.q[so]; D.n[dn] = Sx.n[so]; D.vl[dn] = 0;
+                D.cbase[dn] = Sx.cbase[so]; D.nch[dn] = Sx.nch[so]; D.mv[dn] = Sx.mv[so]; D.midx[dn] = Sx.midx[so];
+            }
+            if (lane == 0) D.cbase[head + b] = ncb;
+            tail += nc;
+        }
+        __syncthreads();
+        head = lim;
+    }
+    if (lane == 0) { gd->arena = a ^ 1; gd->root = 0; gd->next = tail; gd->overflow = 0; }
+}
+
+hipError_t launch_select(const TreeDev& d, const TreeCfg& c, hipStream_t st) {
+    hipLaunchKernelGGL(select_kernel, dim3(d.G), dim3(64), 0, st, d, c);
+    return hipGetLastError();
+}
+hipError_t launch_expand(const TreeDev& d, const TreeCfg& c, hipStream_t st) {
+    hipLaunchKernelGGL(expand_kernel, dim3(d.G), dim3(64), 0, st, d, c);
+    return hipGetLastError();
+}
+hipError_t launch_advance(const TreeDev& d, const int* game_ids_dev, const int* child_slots_dev, int count, hipStream_t st) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(advance_kernel, dim3(count), dim3(64), 0, st, d, game_ids_dev, child_slots_dev, count);
+    return hipGetLastError();
+}
+
+// ---- position-wise encoding.py on device: one wave per position ----
+__global__ __launch_bounds__(64) void encode_positions_kernel(const Pos* pos, int n, float* planes, _Float16* nhwc,
+                                                              uint8_t* mask, int32_t* nlegal, uint16_t* moves, int32_t* idxs) {
+    __shared__ Move smoves[M0_MAX_MOVES];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const Pos p = pos[i];
+    if (planes) {
+        float c7[7];
+        plane_consts(p, c7);
+        const int s = (7 - (lane >> 3)) * 8 + (lane & 7);
+        const int pl = piece_plane(p, s);
+        float* o = planes + (size_t)i * 19 * 64;
+        for (int k = 0; k < 12; ++k) o[k * 64 + lane] = pl == k ? 1.f : 0.f;
+        for (int k = 0; k < 7; ++k) o[(12 + k) * 64 + lane] = c7[k];
+    }
+    if (nhwc) encode_nhwc(p, nhwc + (size_t)i * 64 * 32, lane);
+    const int k = gen_legal(p, smoves);
+    __syncthreads();
+    if (mask) for (int j = lane; j < 4672; j += 64) mask[(size_t)i * 4672 + j] = 0;
+    __syncthreads();
+    for (int j = lane; j < M0_MAX_MOVES; j += 64) {
+        int idx = -1;
+        Move m = 0;
+        if (j < k) { m = smoves[j]; idx = move_to_index(p, m); if (mask && idx >= 0) mask[(size_t)i * 4672 + idx] = 1; }
+        if (moves) moves[(size_t)i * M0_MAX_MOVES + j] = m;
+        if (idxs) idxs[(size_t)i * M0_MAX_MOVES + j] = idx;
+    }
+    if (lane == 0 && nlegal) nlegal[i] = k;
+}
+
+hipError_t launch_encode_positions(const Pos* pos_dev, int n, float* planes, _Float16* nhwc, uint8_t* mask,
+                                   int32_t* nlegal, uint16_t* moves, int32_t* idxs, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_positions_kernel, dim3(n), dim3(64), 0, st, pos_dev, n, planes, nhwc, mask, nlegal, moves, idxs);
+    return hipGetLastError();
+}

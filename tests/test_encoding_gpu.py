@@ -1,0 +1,58 @@
+"""GPU parity (bit-exact): device encode_board / legal mask / move order / move_to_index vs the oracle,
+on the reference's own FEN fixtures and test cases, called through the C-ABI (m0_encode_fens)."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import chess_py as ch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KIWIPETE = "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"
+
+
+def test_device_encoding_matches_oracle_on_reference_fens():
+    from matrix0_amd import encoding as enc
+    rows = json.load(gzip.open(os.path.join(GOLDEN, "tactical_legal_counts.json.gz"), "rt"))
+    fens = [r[0] for r in rows]                       # all 10 000
+    planes, mask, moves = enc.encode_fens(fens)
+    for i, (fen, n, _) in enumerate(rows):
+        assert len(moves[i][0]) == n and mask[i].sum() == n
+    for i in range(0, len(fens), 5):
+        b = ch.Board(fens[i])
+        om, oi = ch.legal_moves_with_indices(b)
+        assert moves[i][0] == [m.uci() for m in om], fens[i]       # same ORDER
+        assert moves[i][1] == oi
+        assert np.array_equal(planes[i], ch.encode_board(b))
+        assert np.array_equal(mask[i], ch.get_legal_actions(b))
+
+
+def test_reference_unit_cases_on_device():
+    from matrix0_amd import encoding as enc
+    # tests/test_encoding.py
+    f = "r3k2r/8/8/8/8/8/8/R3K2R w KQkq - 0 1"
+    assert enc.move_to_index(f, "e1g1") != enc.move_to_index(f, "e1c1")
+    assert 0 <= enc.move_to_index("8/8/8/3pP3/8/8/8/8 w - d6 0 2", "e5d6") < 4672
+    f = "8/P7/8/8/8/8/8/4k2K w - - 0 1"
+    assert enc.move_to_index(f, "a7a8n") != enc.move_to_index(f, "a7a8q")
+    planes, mask, moves = enc.encode_fens([ch.START_FEN, KIWIPETE])
+    assert mask[0].sum() == 20 and mask.dtype == bool and mask.shape == (2, 4672)
+    assert len(set(moves[1][1])) == 48
+    e = planes[0]
+    assert e.dtype == np.float32 and np.all(e[0][6, :] == 1.0) and np.all(e[6][1, :] == 1.0)
+    for i in range(12, 17):
+        assert np.all(e[i] == 1.0)
+    with pytest.raises(ValueError):
+        enc.move_to_index(ch.START_FEN, "a1a8")
+    # tests/test_board_tensor.py
+    t = enc.encode_board("rnbqkbnr/pppppppp/8/8/4P3/8/PPPP1PPP/RNBQKBNR b KQkq e3 0 1")
+    assert t[0, 4, 4] == 1.0 and t[6, 1, 0] == 1.0 and np.all(t[12] == 0)
+    assert abs(t[17].mean()) < 1e-6 and abs(t[18].mean() - 0.005025) < 1e-6
+    # tests/test_encoding_random.py
+    perm = enc.build_horizontal_flip_permutation()
+    assert np.array_equal(np.arange(73)[perm][perm], np.arange(73))
+    rot = enc.build_rotate180_permutation()
+    assert np.array_equal(np.arange(73)[rot][rot], np.arange(73))

@@ -1,0 +1,96 @@
+"""End-to-end self-play on the GPU with a small network: games are replayed through the oracle's rules,
+records checked against the reference's NPZ contract (selfplay/internal.py:628-651)."""
+import numpy as np
+import pytest
+
+from oracle import chess_py as ch
+from oracle import mcts_ref as ref
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(planes=19, channels=32, blocks=2, attention_heads=2, policy_size=4672, norm="group", activation="silu",
+           preact=True, policy_factor_rank=16, self_supervised=False)
+CFG = {"seed": 99,
+       "mcts": {"cpuct": 2.5, "cpuct_start": 3.0, "cpuct_end": 2.0, "cpuct_plies": 40, "dirichlet_plies": 30,
+                "selection_jitter": 0.05, "fpu_reduction": 0.1, "draw_penalty": -0.05, "legal_softmax": True,
+                "inference_batch_size": 8, "playout_random_frac": 0.05},
+       "selfplay": {"num_simulations": 48, "max_game_len": 40, "min_resign_plies": 50, "resign_threshold": -0.85,
+                    "opening_random_plies": 6, "temperature_start": 1.2, "temperature_end": 0.3, "temperature_moves": 40,
+                    "draw": {"min_plies": 30, "window": 8, "min_unique": 4, "halfmove_cap": 100}}}
+
+
+def test_selfplay_games_are_legal_and_records_follow_the_contract():
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    be = M0Backend.from_state_dict(NET, net_ref.random_state_dict(NET, seed=1))
+    cfg = eng.selfplay_cfg_from_dict(CFG, concurrent_games=6, total_games=9)
+    e = eng.SelfplayEngine(be, cfg)
+    games = []
+    for _ in range(4000):
+        e.step(8)
+        while True:
+            r = e.poll()
+            if r is None:
+                break
+            games.append(r)
+        if not e.running():
+            break
+    st = e.stats()
+    assert len(games) == 9 and st["games_finished"] == 9 and st["active_games"] == 0
+    assert sorted(g["game_index"] for g in games) == list(range(9))
+    assert st["evals"] > 0 and st["plies"] == sum(g["moves"] for g in games)
+    for g in games:
+        T = g["moves"]
+        assert 1 <= T <= 40
+        assert g["s"].shape == (T, 19, 8, 8) and g["s"].dtype == np.float32
+        assert g["pi"].shape == (T, 4672) and g["pi"].dtype == np.float32
+        assert g["z"].shape == (T,) and g["legal_mask"].shape == (T, 4672) and g["legal_mask"].dtype == np.uint8
+        np.testing.assert_allclose(g["pi"].sum(axis=1), 1.0, atol=1e-4)
+        assert np.all(g["pi"] >= 0) and np.all(g["pi"][g["legal_mask"] == 0] == 0)
+        # replay through the oracle: legality, planes, masks, result
+        b = ch.Board()
+        played = [ch.Move.from_uci(u) for u in g["played"]]
+        n_open = len(played) - T + (1 if False else 0)
+        # plies recorded = searched plies; the last searched ply's move is played unless the game resigned there
+        n_open = len(played) - (T - (1 if g["resigned"] else 0))
+        assert 0 <= n_open <= 6
+        moves = []
+        for i, m in enumerate(played):
+            assert m in b.legal_moves, (i, m)
+            if i >= n_open:
+                t = i - n_open
+                assert np.array_equal(g["s"][t], ch.encode_board(b))
+                assert np.array_equal(g["legal_mask"][t].astype(bool), ch.get_legal_actions(b))
+                assert g["pi"][t][ch.move_to_index(b, m)] > 0          # the played move was visited
+            b.push(m)
+            moves.append(m)
+        turn0 = 1 if (n_open % 2 == 0) else -1
+        signs = np.array([turn0 * (1 if t % 2 == 0 else -1) for t in range(T)], np.float32)
+        if not g["resigned"]:
+            ended = b.is_game_over() or T >= 40 or ref.should_adjudicate_draw(b, moves, CFG["selfplay"]["draw"])
+            assert ended
+            if b.is_game_over(claim_draw=True):
+                assert g["result"] == ref.game_result(b)
+            else:
+                assert abs(g["result"] - g["search_values"][-1]) < 1e-6      # length cap: last root_q (internal.py:594-597)
+        np.testing.assert_allclose(g["z"], g["result"] * signs, atol=1e-6)
+        assert g["draw"] == (g["result"] == 0.0)
+
+
+def test_selfplay_is_deterministic_for_a_seed():
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    be = M0Backend.from_state_dict(NET, net_ref.random_state_dict(NET, seed=1))
+    outs = []
+    for rep in range(2):
+        cfg = eng.selfplay_cfg_from_dict(CFG, concurrent_games=3, total_games=3)
+        e = eng.SelfplayEngine(be, cfg)
+        games = {}
+        while e.running():
+            e.step(16)
+            while (r := e.poll()) is not None:
+                games[r["game_index"]] = r["played"]
+        outs.append(games)
+        e.close()
+    assert outs[0] == outs[1]
