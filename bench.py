@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Self-play throughput benchmark (BASELINE.json metric: self-play games/sec at 800 sims/move,
+ResNet-24 "53M" (R24-320), 1/2/4/8 MI355X).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: for every resident game tree, select up to
+`leaves` leaves (PUCT + virtual loss), encode them into the network input, run the R24-320 forward on the
+whole batch (games x leaves positions), expand + back up, and play the moves of the searches that
+completed (800 simulations per move).  Inputs are resident in HBM; weights are random-init R24-320
+(synthetic: no checkpoint, no dataset).  One process per GPU; games shard across GPUs with no data-path
+collective (RCCL is used only to broadcast the weights from rank 0), so scaling is "weak".
+
+games/sec: games finished in the timed region / time when at least MIN_FINISHED games finish there;
+otherwise (short runs) plies/sec divided by the mean game length in plies from profiles/game_length.json
+(measured by running games to completion with this engine/config; the basis is named in the JSON line).
+
+Extra objects in the JSON line:
+  roofline      dominant kernel = 3x3 320->320 implicit-GEMM conv (MFMA-bound); achieved = algorithmic FLOP /
+                launch time from HIP events around every launch on the launch stream, summed over the timed region
+  cpu_baseline  the CPU oracle (oracle/mcts_ref.py + oracle/net_ref.py, torch CPU fp32) timed on this box's host
+                cores on a bounded sample, rank 0 at N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R24_320 = dict(planes=19, channels=320, blocks=24, attention_heads=20, policy_size=4672, norm="group",
+               activation="silu", preact=True, droppath=0.1, policy_factor_rank=128, self_supervised=True,
+               ssl_tasks=["piece", "threat", "pin", "fork", "control"])
+
+# config.yaml:26-43, 128-163, num_simulations = 800 per the metric
+SELFPLAY_CFG = {
+    "seed": 1234,
+    "mcts": {"cpuct": 2.5, "cpuct_start": 3.0, "cpuct_end": 2.0, "cpuct_plies": 40, "dirichlet_alpha": 0.3,
+             "dirichlet_frac": 0.25, "dirichlet_plies": 30, "selection_jitter": 0.05, "fpu_reduction": 0.1,
+             "draw_penalty": -0.05, "legal_softmax": True, "no_instant_backtrack": True, "value_from_white": False,
+             "virtual_loss": 1.0, "playout_random_frac": 0.05, "enable_entropy_noise": True,
+             "inference_batch_size": 96},
+    "selfplay": {"num_simulations": 800, "max_game_len": 200, "min_resign_plies": 50, "resign_threshold": -0.85,
+                 "opening_random_plies": 12, "temperature_start": 1.2, "temperature_end": 0.3, "temperature_moves": 40,
+                 "draw": {"min_plies": 30, "window": 8, "min_unique": 4, "halfmove_cap": 100}},
+}
+
+PEAK_FP16_DENSE = 2.5e15          # MI355X dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+MIN_FINISHED = 32
+DEFAULT_PLIES_PER_GAME = 150.0
+
+
+def game_length_basis():
+    p = os.path.join(ROOT, "profiles", "game_length.json")
+    try:
+        d = json.load(open(p))
+        return float(d["mean_plies_per_game"]), f"profiles/game_length.json ({d.get('games', '?')} games)"
+    except Exception:
+        return DEFAULT_PLIES_PER_GAME, "default (no calibration file)"
+
+
+def cpu_baseline(seconds: float, plies_per_game: float):
+    """The CPU oracle on a bounded sample of the same workload: reference search semantics (batch of 96 leaves,
+    transposition table, no virtual loss) + fp32 torch-CPU forward of R24-320, start position, 800-sim moves
+    until `seconds` have elapsed (at least one 96-leaf batch)."""
+    import numpy as np
+    import torch
+    from oracle import chess_py as ch
+    from oracle import mcts_ref as ref
+    from oracle import net_ref
+
+    cores = torch.get_num_threads()
+    sd = net_ref.random_state_dict(R24_320, seed=0)
+
+    def infer(x):
+        p, v, _ = net_ref.forward(sd, R24_320, torch.from_numpy(np.ascontiguousarray(x)))
+        return p.numpy(), v.numpy()
+
+    m = dict(SELFPLAY_CFG["mcts"])
+    cfg = ref.MCTSConfig.from_dict(dict(m, use_tt=True, virtual_loss_active=False, numerics="reference"))
+    o = ref.MCTS(cfg, infer, seed=1234, game=0)
+    b = ch.Board()
+    root = ref.Node()
+    logits, _ = o._infer_one(b)
+    o.expand(root, b, logits)
+    t0 = time.perf_counter()
+    sims = 0
+    while True:
+        o.run_batched(b, root, 96)
+        sims += 96
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    sims_per_s = sims / dt
+    return {"value": sims_per_s / (800.0 * plies_per_game), "unit": "games/s", "cores": int(cores), "kind": "port",
+            "sims_per_s": round(sims_per_s, 2),
+            "sample": f"{sims} simulations ({sims // 96} batches of 96 leaves) of one 800-sim search from the start "
+                      f"position, oracle MCTS (TT, no virtual loss) + torch-CPU fp32 R24-320 on {cores} threads, "
+                      f"{dt:.1f} s; games/s = sims/s / (800 x {plies_per_game:.1f} plies)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU (BASELINE configs[1])")
+    ap.add_argument("--leaves", type=int, default=16, help="leaves per tree and step (<= mcts.inference_batch_size)")
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--ssl", action="store_true", help="run the 5 SSL heads in every evaluation (configs[3])")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import net_ref                      # only random_state_dict (weight synthesis) + cpu_baseline
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # weights: rank 0 synthesises, RCCL broadcast (the optional weight broadcast of the north star)
+    shapes = net_ref.param_shapes(R24_320)
+    if rank == 0:
+        sd = net_ref.random_state_dict(R24_320, seed=0)
+    if distributed:
+        names = list(shapes.keys())
+        total = sum(int(np.prod(shapes[k])) if shapes[k] else 1 for k in names)
+        blob = torch.empty(total, dtype=torch.float32, device="cuda")
+        if rank == 0:
+            blob.copy_(torch.cat([sd[k].reshape(-1).float() for k in names]))
+        dist.broadcast(blob, src=0)
+        flat = blob.cpu()
+        sd, off = {}, 0
+        for k in names:
+            n = int(np.prod(shapes[k])) if shapes[k] else 1
+            sd[k] = flat[off:off + n].reshape(shapes[k])
+            off += n
+    be = M0Backend.from_state_dict(R24_320, sd, device_index=local_rank)
+    flops_eval = be.flops_per_position(with_ssl=args.ssl)
+
+    cfg_dict = json.loads(json.dumps(SELFPLAY_CFG))
+    cfg_dict["selfplay"]["num_simulations"] = args.sims
+    cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
+                                     first_game_index=rank * args.games, leaves_per_step=args.leaves,
+                                     virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
+    e = eng.SelfplayEngine(be, cfg)
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        e.step(args.warmup)
+    be.profile_enable(True)
+    be.profile_get(reset=True)
+    s0 = e.stats()
+    sync()
+    t0 = time.perf_counter()
+    e.step(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    s1 = e.stats()
+    conv_ms, conv_flop, conv_launches = be.profile_get(reset=True)
+    be.profile_enable(False)
+
+    d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total")}
+    vec = torch.tensor([dt, d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
+                        d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"]], dtype=torch.float64, device="cuda")
+    if distributed:
+        tmax = vec[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        vec[0] = tmax[0]
+    dt_max, evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims = [float(x) for x in vec.cpu()]
+
+    if rank == 0:
+        ppg, basis_src = game_length_basis()
+        if gfin >= MIN_FINISHED * args.gpus:
+            games_per_s = gfin / dt_max
+            basis = f"{int(gfin)} games finished in the timed region"
+        else:
+            games_per_s = (sims / dt_max) / (args.sims * ppg)
+            basis = f"simulations/s / ({args.sims} sims per move x {ppg:.1f} plies per game [{basis_src}])"
+        achieved = (conv_flop / (conv_ms * 1e-3)) if conv_ms > 0 else 0.0
+        traffic = None
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        out = {
+            "metric": "self-play games/sec at 800 sims/move, ResNet-24 53M; 1/2/4/8 MI355X",
+            "value": games_per_s, "unit": "games/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.games} concurrent games per GPU x {args.gpus} GPU, {args.sims} sims/move, "
+                                   f"R24-320 (57.56M params, {flops_eval / 1e9:.4f} GFLOP/eval) fp16 MFMA, {args.leaves} leaves/tree/step"
+                                   + (", 5 SSL heads in forward" if args.ssl else ""),
+                       "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"},
+            "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
+            "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
+            "time_split_ms_per_step": {"net": ms_net / args.gpus / max(1, args.steps), "tree": ms_tree / args.gpus / max(1, args.steps),
+                                       "host": ms_host / args.gpus / max(1, args.steps)},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel<9,2,5,64> (3x3 320->320 implicit GEMM)",
+                         "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
+                         "launches": int(conv_launches), "avg_launch_us": (conv_ms * 1e3 / conv_launches) if conv_launches else None,
+                         "whole_net_frac": (evals * flops_eval / dt_max) / (PEAK_FP16_DENSE * args.gpus)},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, ppg)
+        print(json.dumps(out), flush=True)
+    e.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

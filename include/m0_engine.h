@@ -96,6 +96,11 @@ double m0_net_flops_per_position(const m0_net* net, int with_ssl);
 /* Timed forward on synthetic resident inputs (bench/roofline): runs `iters` forwards of batch B on the
  * net's stream and returns the mean milliseconds per forward measured with HIP events on that stream. */
 int m0_net_bench_forward(m0_net* net, int B, int iters, int with_ssl, float* ms_per_forward);
+/* Roofline instrumentation of the dominant kernel (3x3 C->C implicit-GEMM conv): when enabled, every launch is
+ * bracketed by HIP events on the launch stream.  get: accumulated milliseconds, algorithmic FLOP
+ * (2 * rows * Cout * Cin * 9 per launch) and launches since the last reset. */
+int m0_net_profile_enable(m0_net* net, int on);
+int m0_net_profile_get(m0_net* net, double* conv_ms, double* conv_flop, int64_t* launches, int reset);
 
 
 /* ---- position-wise azchess/encoding.py on the device (batched) ----

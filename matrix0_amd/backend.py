@@ -119,6 +119,15 @@ class M0Backend:
                    "m0_net_bench_forward")
         return float(ms.value)
 
+    def profile_enable(self, on: bool = True) -> None:
+        _lib.check(self._L.m0_net_profile_enable(self._h, int(on)), "m0_net_profile_enable")
+
+    def profile_get(self, reset: bool = False):
+        """(ms, algorithmic FLOP, launches) of the 3x3 conv kernel, HIP events on its launch stream."""
+        ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        _lib.check(self._L.m0_net_profile_get(self._h, C.byref(ms), C.byref(fl), C.byref(n), int(reset)), "m0_net_profile_get")
+        return ms.value, fl.value, n.value
+
     @property
     def handle(self):
         return self._h

@@ -142,6 +142,23 @@ int m0_net_ssl_channels(const m0_net* n) { return n ? n->net->ssl_channels_total
 int64_t m0_net_param_count(const m0_net* n) { return n ? (int64_t)n->net->param_count() : 0; }
 double m0_net_flops_per_position(const m0_net* n, int with_ssl) { return n ? n->net->flops_per_position(with_ssl != 0) : 0.0; }
 
+int m0_net_profile_enable(m0_net* n, int on) {
+    if (!n) { m0_set_error("net is null"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(n->mu);
+    n->net->set_profile(on != 0);
+    return M0_OK;
+}
+
+int m0_net_profile_get(m0_net* n, double* conv_ms, double* conv_flop, int64_t* launches, int reset) {
+    if (!n) { m0_set_error("net is null"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(n->mu);
+    if (conv_ms) *conv_ms = n->net->prof_conv_ms();
+    if (conv_flop) *conv_flop = n->net->prof_conv_flop();
+    if (launches) *launches = n->net->prof_conv_launches();
+    if (reset) n->net->reset_profile();
+    return M0_OK;
+}
+
 int m0_net_bench_forward(m0_net* n, int B, int iters, int with_ssl, float* ms_per_forward) {
     if (!n || !ms_per_forward || B <= 0 || iters <= 0) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(n->mu);
@@ -179,6 +196,7 @@ int m0_net_bench_forward(m0_net* n, int B, int iters, int with_ssl, float* ms_pe
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_per_forward = ms / iters;
+    n->net->harvest_profile();
     return M0_OK;
 }
 

@@ -72,6 +72,14 @@ public:
     size_t param_count() const { return nparams_; }
     double flops_per_position(bool with_ssl) const;
     _Float16* input_nhwc() { return X0_; }   // engine-side encoders write here directly
+    // Dominant-kernel timing (roofline): when enabled every 3x3 C->C conv launch is bracketed by HIP events on
+    // the launch stream; harvest after the stream has been synchronised.
+    void set_profile(bool on) { profile_ = on; }
+    void harvest_profile();
+    double prof_conv_ms() const { return prof_ms_; }
+    double prof_conv_flop() const { return prof_flop_; }
+    long prof_conv_launches() const { return prof_launches_; }
+    void reset_profile() { prof_ms_ = 0; prof_flop_ = 0; prof_launches_ = 0; }
 
 private:
     m0_net_cfg cfg_;
@@ -98,6 +106,13 @@ private:
     NormParams vh1_n_, vh4_n_;
     std::vector<SslHeadW> ssl_;
     uint64_t* mask_dev_ = nullptr;
+
+    bool profile_ = false;
+    std::vector<hipEvent_t> pev_;
+    std::vector<double> pflop_;
+    size_t pev_used_ = 0;
+    double prof_ms_ = 0, prof_flop_ = 0;
+    long prof_launches_ = 0;
 
     // workspace
     int wsB_ = 0, wsM_ = 0;

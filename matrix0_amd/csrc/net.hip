@@ -52,6 +52,7 @@ Net::Net(const m0_net_cfg& cfg, int device) : cfg_(cfg), device_(device) {
 }
 
 Net::~Net() {
+    for (hipEvent_t e : pev_) (void)hipEventDestroy(e);
     for (void* p : dev_allocs_) (void)hipFree(p);
     for (void* p : ws_allocs_) (void)hipFree(p);
 }
@@ -359,7 +360,31 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
     a.pro_act = pro_act; a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale;
-    return launch_conv_gemm(a, g.taps, st);
+    const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
+    if (timed) {
+        if (pev_used_ + 2 > pev_.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory; pev_.push_back(e); }
+        }
+        (void)hipEventRecord(pev_[pev_used_], st);
+    }
+    hipError_t rc = launch_conv_gemm(a, g.taps, st);
+    if (timed) {
+        (void)hipEventRecord(pev_[pev_used_ + 1], st);
+        pev_used_ += 2;
+        pflop_.push_back(2.0 * (double)Mvalid * (double)g.N * (double)g.Cin * 9.0);
+    }
+    return rc;
+}
+
+void Net::harvest_profile() {
+    for (size_t i = 0; i + 1 < pev_used_; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pev_[i], pev_[i + 1]) == hipSuccess) {
+            prof_ms_ += ms; prof_flop_ += pflop_[i / 2]; prof_launches_++;
+        }
+    }
+    pev_used_ = 0;
+    pflop_.clear();
 }
 
 #define KCHK(x)                                                                           \

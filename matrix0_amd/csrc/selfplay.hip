@@ -79,6 +79,7 @@ struct m0_selfplay {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     std::mutex mu;
     std::vector<Sample> hsamples;
+    std::vector<int> prev_done;           // per slot: simulations already credited to stats.sims
     int last_rows = 0;
 };
 
@@ -136,6 +137,7 @@ void arm_search(m0_selfplay* sp, int slot, const Pos& pos, const RepWindow& win,
     g.root_fresh = fresh ? 1 : 0;
     g.flip_root_v = (sp->cfg.value_from_white && pos.turn == BLACK) ? 1 : 0;
     g.finished = 0; g.nsamples = 0;
+    sp->prev_done[slot] = 0;
     push_hist(sp, slot, win);
 }
 
@@ -321,6 +323,7 @@ int one_step(m0_selfplay* sp, std::string& err) {
     if (launch_expand(sp->d, sp->tc, sp->stream) != hipSuccess) { err = "expand launch failed"; return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev3, sp->stream);
     if (sync_games_d2h(sp) != 0) { err = std::string("step failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
+    if (sp->net) sp->net->harvest_profile();
     float ms_sel = 0, ms_net = 0, ms_exp = 0;
     (void)hipEventElapsedTime(&ms_sel, sp->ev0, sp->ev1);
     (void)hipEventElapsedTime(&ms_net, sp->ev1, sp->ev2);
@@ -330,16 +333,18 @@ int one_step(m0_selfplay* sp, std::string& err) {
     const double t1 = now_ms();
     // host: finished searches -> moves, game ends, restarts
     bool any = false;
-    int sims_step = 0;
-    for (int s = 0; s < sp->G; ++s) if (sp->hg[s].active) { sims_step += 0; if (sp->hg[s].finished) any = true; }
-    (void)sims_step;
+    for (int s = 0; s < sp->G; ++s) {
+        if (!sp->hg[s].active) continue;
+        const int delta = sp->hg[s].sims_done - sp->prev_done[s];
+        if (delta > 0) { sp->stats.sims += (uint64_t)delta; sp->prev_done[s] = sp->hg[s].sims_done; }
+        if (sp->hg[s].finished) any = true;
+    }
     std::vector<int> ids, slots;
     if (any) {
         (void)hipMemcpy(sp->hres.data(), sp->d.results, sizeof(RootResult) * sp->G, hipMemcpyDeviceToHost);
         for (int s = 0; s < sp->G; ++s) {
             if (!(sp->hg[s].active && sp->hg[s].finished)) continue;
             if (sp->hg[s].overflow) sp->stats.arena_overflows++;
-            sp->stats.sims += (uint64_t)sp->hg[s].sims_done;
             finish_search(sp, s, ids, slots);
         }
         // refill free slots
@@ -423,6 +428,7 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     sp->games.assign(sp->G, HostGame());
     sp->hres.resize(sp->G);
     sp->hsamples.resize((size_t)sp->G * sp->L);
+    sp->prev_done.assign(sp->G, 0);
     (void)hipEventCreate(&sp->ev0); (void)hipEventCreate(&sp->ev1); (void)hipEventCreate(&sp->ev2); (void)hipEventCreate(&sp->ev3);
     if (sp->net) {
         std::string err;
