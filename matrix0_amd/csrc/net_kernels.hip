@@ -25,8 +25,21 @@
 #include <stdint.h>
 #include "net_kernels.h"
 
+#include <type_traits>
+#include <utility>
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+
+// Compile-time loop: the body sees its index as an integral_constant, so every accumulator index is a
+// constant in the AST (a runtime- or late-unrolled index keeps the MFMA accumulators in scratch memory).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -97,12 +110,12 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     __syncthreads();
 
     float16v acc[2][NT];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    static_for<0, 2>([&](auto mi) {
+        static_for<0, NT>([&](auto ni) {
+            acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        });
+    });
 
     // per-lane LDS base of its two A rows (squares lane&31 and 32+(lane&31) of board wm)
     int apix[2];
@@ -191,57 +204,60 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
         }
         const int tapoff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
         const _Float16* Wb = W_lds + (s & 1) * W_ELEMS + (wn * NT * 32 + (lane & 31)) * AST + khalf;
-#pragma unroll
-        for (int kk = 0; kk < KC / 16; ++kk) {
-            half8 af[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi] = *reinterpret_cast<const half8*>(A_lds + (apix[mi] + tapoff) * AST + kk * 16 + khalf);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
+        static_for<0, KC / 16>([&](auto kk_) {
+            constexpr int kk = decltype(kk_)::value;
+            half8 af0 = *reinterpret_cast<const half8*>(A_lds + (apix[0] + tapoff) * AST + kk * 16 + khalf);
+            half8 af1 = *reinterpret_cast<const half8*>(A_lds + (apix[1] + tapoff) * AST + kk * 16 + khalf);
+            static_for<0, NT>([&](auto ni_) {
+                constexpr int ni = decltype(ni_)::value;
                 half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 32 * AST + kk * 16);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf, acc[mi][ni], 0, 0, 0);
-            }
-        }
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf, acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf, acc[1][ni], 0, 0, 0);
+            });
+        });
     }
 
     // ---------------- epilogue ----------------
-    const int N = a.N;
+    // (everything indexed with compile-time constants: a runtime-indexed accumulator goes to scratch)
     const int ldo = a.ldo;
     const int rowbase = m0 + wm * 64 + 4 * (lane >> 5);
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int col = n0 + wn * NT * 32 + ni * 32 + (lane & 31);
-        const bool colok = col < N;
-        const float bias = (a.bias != nullptr && colok) ? a.bias[col] : 0.f;
+    const int colbase = n0 + wn * NT * 32 + (lane & 31);
+    const int epi_act = a.epi_act;
+    const float oscale = a.out_scale;
+    const bool has_mul = a.mul != nullptr;
+    const bool f32out = a.out_f32 != 0;
+    const bool want_stats = a.out_stats != nullptr;
+    static_for<0, NT>([&](auto ni_) {
+        constexpr int ni = decltype(ni_)::value;
+        const int col = colbase + ni * 32;
+        const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
         float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+        static_for<0, 2>([&](auto mi_) {
+            constexpr int mi = decltype(mi_)::value;
+            const float16v av = acc[mi][ni];
+            static_for<0, 16>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
                 const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                float v = acc[mi][ni][r] + bias;
-                v = act_apply(v, a.epi_act);
-                if (a.mul != nullptr && colok) v *= (float)a.mul[(size_t)row * ldo + col];
-                v *= a.out_scale;
+                float v = av[r] + bias;
+                if (epi_act != ACT_NONE) v = act_apply(v, epi_act);
+                if (has_mul) v *= (float)a.mul[(size_t)row * ldo + col];
+                v *= oscale;
                 s += v; ss += v * v;
-                if (colok && row < a.Mvalid) {
-                    if (a.out_f32) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
+                if (row < a.Mvalid) {
+                    if (f32out) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
                     else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
                 }
-            }
-        }
-        if (a.out_stats != nullptr) {
+            });
+        });
+        if (want_stats) {
             s += __shfl_xor(s, 32);
             ss += __shfl_xor(ss, 32);
-            if (lane < 32 && colok) {
-                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * N + col) * 2;
+            if (lane < 32) {
+                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * a.N + col) * 2;
                 st[0] = s; st[1] = ss;
             }
         }
-    }
+    });
 }
 
 template <int TAPS, int WN, int NT, int KC>
