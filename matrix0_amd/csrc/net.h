@@ -117,7 +117,7 @@ private:
     // workspace
     int wsB_ = 0, wsM_ = 0;
     _Float16 *X0_ = nullptr, *XA_ = nullptr, *XB_ = nullptr, *T1_ = nullptr, *T2_ = nullptr, *QKV_ = nullptr,
-             *O_ = nullptr;
+             *O_ = nullptr, *AA_ = nullptr;
     float *SX_ = nullptr, *S1_ = nullptr, *S2_ = nullptr;
     _Float16 *PH_ = nullptr, *PH2_ = nullptr, *VH_ = nullptr, *VH2_ = nullptr, *F1_ = nullptr, *F2_ = nullptr,
              *F3_ = nullptr, *F4_ = nullptr, *SH_ = nullptr, *SH2_ = nullptr, *SO_ = nullptr;
@@ -131,6 +131,6 @@ private:
     float* upload_f32(const std::vector<float>& v);
     void* dalloc(size_t bytes, bool ws);
     hipError_t run_gemm(const PackedGemm& g, const _Float16* in, void* out, int Mrows, int Mvalid,
-                        const float* in_stats, const NormParams* in_norm, int pro_act, int epi_act,
-                        const _Float16* mul, float* out_stats, bool out_f32, float out_scale, hipStream_t st);
+                        const NormParams* out_norm, int epi_act, const _Float16* mul, float* out_stats,
+                        bool out_f32, float out_scale, hipStream_t st);
 };

@@ -117,6 +117,8 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
                     kk = sq * k_perm_ch + c;
                 }
                 int chunk = kk / KC, kc = kk % KC;
+                if (KC == 64)   // big tile: LDS image order, 16-byte chunk index XOR (row>>1)&7 (conv_big_kernel)
+                    kc = (((kc >> 3) ^ ((n >> 1) & 7)) << 3) | (kc & 7);
                 p[(((size_t)t * nchunk + chunk) * N_pad + n) * KC + kc] = (_Float16)v;
             }
     g.w = (_Float16*)dalloc(p.size() * 2, false);
@@ -200,7 +202,10 @@ int Net::finalize(std::string& err) {
                     for (int c = 0; c < C; ++c) w1t[(size_t)c * hd + j] = w1->data[(size_t)j * C + c];
                 r.se_w1 = upload_f32(w1t);
                 r.se_b1 = upload_f32(b1->data);
-                r.se_w2 = upload_f32(w2->data);               // already [C][hd]
+                std::vector<float> w2t((size_t)hd * C);       // [hd][C] from [C][hd]: coalesced across channels
+                for (int c = 0; c < C; ++c)
+                    for (int j = 0; j < hd; ++j) w2t[(size_t)j * C + c] = w2->data[(size_t)c * hd + j];
+                r.se_w2 = upload_f32(w2t);
                 r.se_b2 = upload_f32(b2->data);
             }
         } else {
@@ -329,7 +334,7 @@ int Net::ensure_workspace(int B, std::string& err) {
     auto H = [&](size_t elems) { return (_Float16*)dalloc(elems * 2, true); };
     auto F = [&](size_t elems) { return (float*)dalloc(elems * 4, true); };
     X0_ = H(nb * 64 * 32);
-    XA_ = H(nb * 64 * C); XB_ = H(nb * 64 * C); T1_ = H(nb * 64 * C); T2_ = H(nb * 64 * C);
+    XA_ = H(nb * 64 * C); XB_ = H(nb * 64 * C); T1_ = H(nb * 64 * C); T2_ = H(nb * 64 * C); AA_ = H(nb * 64 * C);
     QKV_ = H(nb * 64 * 3 * C); O_ = H(nb * 64 * C);
     SX_ = F(nb * Cst * 2); S1_ = F(nb * Cst * 2); S2_ = F(nb * Cst * 2);
     PH_ = H(nh * 64 * 64); PH2_ = H(nh * 64 * 64);
@@ -339,7 +344,7 @@ int Net::ensure_workspace(int B, std::string& err) {
     F2_ = H((size_t)Mfc * ceil_to(2 * C_, 32)); F3_ = H((size_t)Mfc * ceil_to(C_, 32)); F4_ = H((size_t)Mfc * ceil_to(C_, 32));
     SH_ = H(nb * 64 * Cs_); SH2_ = H(nb * 64 * Cs_); SO_ = H(nb * 64 * 32);
     VAL_ = F((size_t)Mfc * 32);
-    if (!X0_ || !XA_ || !XB_ || !T1_ || !T2_ || !QKV_ || !O_ || !SX_ || !S1_ || !S2_ || !PH_ || !PH2_ || !VH_ ||
+    if (!X0_ || !XA_ || !XB_ || !AA_ || !T1_ || !T2_ || !QKV_ || !O_ || !SX_ || !S1_ || !S2_ || !PH_ || !PH2_ || !VH_ ||
         !VH2_ || !F1_ || !F2_ || !F3_ || !F4_ || !SH_ || !SH2_ || !SO_ || !VAL_) {
         err = "workspace hipMalloc failed";
         wsB_ = wsM_ = 0;
@@ -350,16 +355,15 @@ int Net::ensure_workspace(int B, std::string& err) {
 }
 
 hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int Mrows, int Mvalid,
-                         const float* in_stats, const NormParams* in_norm, int pro_act, int epi_act,
-                         const _Float16* mul, float* out_stats, bool out_f32, float out_scale, hipStream_t st) {
+                         const NormParams* out_norm, int epi_act, const _Float16* mul, float* out_stats,
+                         bool out_f32, float out_scale, hipStream_t st) {
     GemmArgs a;
     a.in = in; a.w = g.w; a.out = out;
-    a.in_stats = in_stats;
-    a.gamma = in_norm ? in_norm->gamma : nullptr;
-    a.beta = in_norm ? in_norm->beta : nullptr;
+    a.gn_gamma = out_norm ? out_norm->gamma : nullptr;
+    a.gn_beta = out_norm ? out_norm->beta : nullptr;
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
-    a.pro_act = pro_act; a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale;
+    a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale;
     const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {
@@ -414,8 +418,11 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         KCHK(launch_planes_to_nhwc(planes_dev, X0_, B, cfg_.planes, st));
         x0 = X0_;
     }
+    const bool big = conv_gemm_tile_n(C, C) == 320;     // fused GN epilogue available (C % 320 == 0)
+    // ew: elementwise glue; y2/gn2 = pre-activated input of the NEXT residual block (its bn1), or null
     auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
-                  const float* pos, const NormParams* ln, _Float16* y, float* ost, int Cc, int boards) -> hipError_t {
+                  const float* pos, const NormParams* ln, _Float16* y, float* ost, const NormParams* next_bn1,
+                  _Float16* y2, int Cc, int boards) -> hipError_t {
         EwArgs e;
         memset(&e, 0, sizeof(e));
         e.t = t; e.t_stats = tst;
@@ -424,74 +431,98 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         e.res = res; e.posenc = pos;
         if (ln) { e.ln_g = ln->gamma; e.ln_b = ln->beta; }
         e.y = y; e.out_stats = ost; e.C = Cc; e.act = act; e.stats_from_rounded = 0;
+        if (next_bn1 && y2) { e.y2 = y2; e.gn2_gamma = next_bn1->gamma; e.gn2_beta = next_bn1->beta; }
         return launch_ew_board(e, boards, st);
     };
+    // bn1 of the residual block that consumes the stream right after tower position `pos` (null if the
+    // next executed layer is attention or the tower ends there)
+    auto next_bn1_after = [&](size_t pos) -> const NormParams* {
+        for (size_t j = pos + 1; j < tower_.size(); ++j) {
+            if (tower_[j].kind == 1) { if (tower_[j].skip) continue; return nullptr; }
+            return &res_[tower_[j].index].bn1;
+        }
+        return nullptr;
+    };
+    const NormParams* first_bn1 = nullptr;
+    for (size_t j = 0; j < tower_.size(); ++j) {
+        if (tower_[j].kind == 1) { if (tower_[j].skip) continue; break; }
+        first_bn1 = &res_[tower_[j].index].bn1; break;
+    }
 
     // stem (resnet.py:314-318) + chess features (229-244)
-    KCHK(run_gemm(stem_, x0, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, cfg_.chess_features ? posenc_ : nullptr, nullptr, XA_, SX_, C, Bp));
+    KCHK(run_gemm(stem_, x0, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
     _Float16* xa = XA_;
     _Float16* xb = XB_;
     if (cfg_.chess_features) {
+        KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, posenc_, nullptr, xa, nullptr, nullptr, nullptr, C, Bp));
         if (cfg_.piece_square_tables) {
-            KCHK(run_gemm(pst_, xa, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-            KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+            KCHK(run_gemm(pst_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, nullptr, nullptr, C, Bp));
             std::swap(xa, xb);
         }
-        KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-        KCHK(ew(T1_, S1_, &inter_n_, nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+        KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+        KCHK(ew(T1_, S1_, &inter_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, first_bn1, AA_, C, Bp));
         std::swap(xa, xb);
+    } else {
+        KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, nullptr, nullptr, xa, nullptr, first_bn1, AA_, C, Bp));
     }
     // tower
-    for (auto& L : tower_) {
+    for (size_t li = 0; li < tower_.size(); ++li) {
+        const TowerLayer& L = tower_[li];
         if (L.kind == 0) {
             const ResBlockW& r = res_[L.index];
-            // pre-activation block, resnet.py:45-51: GN+act fused into the consuming conv's prologue
-            KCHK(run_gemm(r.conv1, xa, T1_, Mc, Mc, SX_, &r.bn1, act, 0, nullptr, S1_, false, 1.f, st));
-            KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, S1_, &r.bn2, act, 0, nullptr, S2_, false, 1.f, st));
-            KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, SX_, C, Bp));
+            // pre-activation block (resnet.py:45-51): AA_ = act(GN1(x)) comes from the previous ew; conv1's
+            // epilogue applies GN2+act in registers (big tile) so conv2 also reads a ready operand
+            if (big) {
+                KCHK(run_gemm(r.conv1, AA_, T1_, Mc, Mc, &r.bn2, act, nullptr, nullptr, false, 1.f, st));
+            } else {
+                KCHK(run_gemm(r.conv1, AA_, T2_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+                KCHK(ew(T2_, S1_, &r.bn2, nullptr, nullptr, nullptr, nullptr, T1_, nullptr, nullptr, nullptr, C, Bp));
+            }
+            KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, nullptr, 0, nullptr, S2_, false, 1.f, st));
+            KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
             std::swap(xa, xb);
         } else {
             if (L.skip) continue;
             const AttnW& w = att_[L.index];
-            KCHK(run_gemm(w.qkv, xa, QKV_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
+            KCHK(run_gemm(w.qkv, xa, QKV_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             AttnArgs aa;
             aa.qkv = QKV_; aa.rel_bias = w.rel_bias; aa.mask = mask_dev_; aa.o = O_;
             aa.B = Bp; aa.H = cfg_.attention_heads; aa.C = C; aa.mix = cfg_.attention_unmasked_mix;
             aa.inv_sqrt_d = 1.f / sqrtf((float)(C / cfg_.attention_heads));
             KCHK(launch_attn_core(aa, st));
-            KCHK(run_gemm(w.proj, O_, T1_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
-            KCHK(ew(T1_, nullptr, nullptr, nullptr, xa, nullptr, &w.ln, xb, SX_, C, Bp));
+            KCHK(run_gemm(w.proj, O_, T1_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
+            KCHK(ew(T1_, nullptr, nullptr, nullptr, xa, nullptr, &w.ln, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
             std::swap(xa, xb);
         }
     }
     // policy head (resnet.py:699-711)
-    KCHK(run_gemm(ph_conv_, xa, PH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(PH_, S1_, &ph_n_, nullptr, nullptr, nullptr, nullptr, PH2_, nullptr, 64, Bp));
+    KCHK(run_gemm(ph_conv_, xa, PH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(PH_, S1_, &ph_n_, nullptr, nullptr, nullptr, nullptr, PH2_, nullptr, nullptr, nullptr, 64, Bp));
     if (cfg_.policy_factor_rank > 0) {
-        KCHK(run_gemm(pfc1_, PH2_, F1_, Mfc, Mfc, nullptr, nullptr, 0, ACT_RELU, nullptr, nullptr, false, 1.f, st));
-        KCHK(run_gemm(pfc2_, F1_, logits_dev, Mfc, B, nullptr, nullptr, 0, 0, nullptr, nullptr, true, logit_scale_, st));
+        KCHK(run_gemm(pfc1_, PH2_, F1_, Mfc, Mfc, nullptr, ACT_RELU, nullptr, nullptr, false, 1.f, st));
+        KCHK(run_gemm(pfc2_, F1_, logits_dev, Mfc, B, nullptr, 0, nullptr, nullptr, true, logit_scale_, st));
     } else {
-        KCHK(run_gemm(pfc1_, PH2_, logits_dev, Mfc, B, nullptr, nullptr, 0, 0, nullptr, nullptr, true, logit_scale_, st));
+        KCHK(run_gemm(pfc1_, PH2_, logits_dev, Mfc, B, nullptr, 0, nullptr, nullptr, true, logit_scale_, st));
     }
     // value head (resnet.py:721-734)
-    KCHK(run_gemm(vh0_, xa, VH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(VH_, S1_, &vh1_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, 128, Bp));
-    KCHK(run_gemm(vh3_, VH2_, VH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(VH_, S1_, &vh4_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, 128, Bp));
-    KCHK(run_gemm(vfc1_, VH2_, F2_, Mfc, Mfc, nullptr, nullptr, 0, vact, nullptr, nullptr, false, 1.f, st));
-    KCHK(run_gemm(vfc2_, F2_, F3_, Mfc, Mfc, nullptr, nullptr, 0, vact, nullptr, nullptr, false, 1.f, st));
-    KCHK(run_gemm(vgate_, F3_, F4_, Mfc, Mfc, nullptr, nullptr, 0, ACT_SIGMOID, F3_, nullptr, false, 1.f, st));
-    KCHK(run_gemm(vfc3_, F4_, VAL_, Mfc, Mfc, nullptr, nullptr, 0, ACT_TANH, nullptr, nullptr, true, 1.f, st));
+    KCHK(run_gemm(vh0_, xa, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(VH_, S1_, &vh1_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
+    KCHK(run_gemm(vh3_, VH2_, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+    KCHK(ew(VH_, S1_, &vh4_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
+    KCHK(run_gemm(vfc1_, VH2_, F2_, Mfc, Mfc, nullptr, vact, nullptr, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vfc2_, F2_, F3_, Mfc, Mfc, nullptr, vact, nullptr, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vgate_, F3_, F4_, Mfc, Mfc, nullptr, ACT_SIGMOID, F3_, nullptr, false, 1.f, st));
+    KCHK(run_gemm(vfc3_, F4_, VAL_, Mfc, Mfc, nullptr, ACT_TANH, nullptr, nullptr, true, 1.f, st));
     KCHK(hipMemcpy2DAsync(value_dev, 4, VAL_, 32 * 4, 4, B, hipMemcpyDeviceToDevice, st));
     // ssl heads (resnet.py:738-745)
     if (ssl_dev && !ssl_.empty()) {
         const int ctot = ssl_channels_total();
         int coff = 0;
         for (auto& h : ssl_) {
-            KCHK(run_gemm(h.c0, xa, SH_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, S1_, false, 1.f, st));
-            KCHK(ew(SH_, S1_, &h.n, nullptr, nullptr, nullptr, nullptr, SH2_, nullptr, Cs_, Bp));
-            KCHK(run_gemm(h.c1, SH2_, SO_, Mc, Mc, nullptr, nullptr, 0, 0, nullptr, nullptr, false, 1.f, st));
+            KCHK(run_gemm(h.c0, xa, SH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(ew(SH_, S1_, &h.n, nullptr, nullptr, nullptr, nullptr, SH2_, nullptr, nullptr, nullptr, Cs_, Bp));
+            KCHK(run_gemm(h.c1, SH2_, SO_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             KCHK(launch_nhwc_to_nchw_f32(SO_, ssl_dev, B, 32, h.out_ch, ctot, coff, st));
             coff += h.out_ch;
         }

@@ -7,11 +7,10 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_LEAKY = 3, ACT_SIGMOID = 4,
 
 struct GemmArgs {
     const _Float16* in;      // [Mrows][Cin]
-    const _Float16* w;       // packed [taps][Cin/KC][Npad][KC]
+    const _Float16* w;       // packed [taps][Cin/KC][Npad][KC] (big tile: 16-byte chunks XOR-swizzled, see pack_gemm)
     void* out;               // [Mrows][ldo] fp16 | f32
-    const float* in_stats;   // [Mrows/64][Cin][2] (sum, sumsq) -> GroupNorm16 prologue ; null = none
-    const float* gamma;      // [Cin]
-    const float* beta;       // [Cin]
+    const float* gn_gamma;   // [N]: epilogue GroupNorm16 (+epi_act) over each board's 64 rows, big tile only
+    const float* gn_beta;    // [N]
     const float* bias;       // [N] or null
     const _Float16* mul;     // [Mrows][ldo] or null
     float* out_stats;        // [Mrows/64][N][2] or null
@@ -21,7 +20,6 @@ struct GemmArgs {
     int N;                   // valid output columns
     int Npad;                // packed columns (multiple of the N tile)
     int ldo;                 // output row stride (elements)
-    int pro_act;
     int epi_act;
     int out_f32;
     float out_scale;
@@ -34,7 +32,7 @@ struct EwArgs {
     const float* gn_beta;
     const float* se_w1;      // [C][Hd] (transposed), SE gate when non-null (and gn null)
     const float* se_b1;
-    const float* se_w2;      // [C][Hd]
+    const float* se_w2;      // [Hd][C] (transposed)
     const float* se_b2;
     const _Float16* res;     // [B][64][C] or null
     const float* posenc;     // [64][C] or null
@@ -42,6 +40,9 @@ struct EwArgs {
     const float* ln_b;
     _Float16* y;             // [B][64][C]
     float* out_stats;        // [B][C][2] or null
+    _Float16* y2;            // [B][64][C] or null: act(GroupNorm16(y; gn2_*)), the next block's conv1 input
+    const float* gn2_gamma;
+    const float* gn2_beta;
     int C;
     int se_hidden;
     int act;

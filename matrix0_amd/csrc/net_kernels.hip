@@ -8,14 +8,16 @@
 // wave-local.
 //
 // Kernels:
-//   conv_gemm_kernel<TAPS,WN,NT,KC>  implicit-GEMM 3x3 / 1x1 conv and FC layers
-//       on v_mfma_f32_32x32x16_f16, fp32 accumulate.  WG tile = 256 rows
-//       (4 boards) x WN*NT*32 output channels; input staged once per K-chunk in
-//       a zero-bordered 10x10 halo image in LDS and re-read for all 9 taps.
-//       Optional prologue: GroupNorm(+activation) of the *input* applied while
-//       staging (statistics come from the producer's epilogue).
-//       Epilogue: bias / activation / multiply / scale, fp16 or fp32 store,
-//       per-(board,channel) sum and sum-of-squares for the next norm.
+//   conv_big_kernel<TAPS>  the hot kernel: implicit-GEMM 3x3 / 1x1 conv (and wide FC layers) on
+//       v_mfma_f32_32x32x16_f16, fp32 accumulate.  WG = 8 waves, tile = 256 rows (4 boards) x 320
+//       output channels, K stepped as (64-channel chunk, tap).  Both operands go global -> LDS by
+//       global_load_lds (16 B/lane, no VGPR staging): the 64-channel slice of the 4 boards once per
+//       chunk (double-buffered, reused by all 9 taps through shifted reads; out-of-board taps read a
+//       shared zero pixel) and one 320x64 weight stage per step (double-buffered, pre-swizzled on the
+//       host).  128-byte LDS rows, 16-byte chunk index XOR (row>>1)&7 -> conflict-free ds_read_b128.
+//       Epilogue: bias/act/mul/scale + per-(board,channel) sums, or a fused GroupNorm16+activation
+//       over the wave's own board (a wave holds all 64 rows of one board x 10 whole groups).
+//   conv_gemm_kernel<TAPS,1,1,32>  generic small-tile variant (any N%32==0, Cin%32==0): stem, heads, FCs.
 //   ew_board_kernel   per-board elementwise glue: GN+act, SE gate, residual add,
 //       positional encoding, LayerNorm over C, output statistics.
 //   attn_core_kernel  ChessAttention scores/softmax/PV for one (board, head).
@@ -72,7 +74,6 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* A_lds = reinterpret_cast<_Float16*>(smem);
     _Float16* W_lds = A_lds + A_ELEMS;                    // 2 buffers
-    float* gstat = reinterpret_cast<float*>(W_lds + 2 * W_ELEMS);  // [4 boards][Cin/16][2] mean,rstd
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,28 +85,11 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     const int Cin = a.Cin;
     const int nchunk = Cin / KC;
     const int Npad = a.Npad;
-    const bool pro = a.in_stats != nullptr;
 
     // zero the halo image once (borders stay zero for the whole kernel)
     if (TAPS == 9) {
         for (int i = tid; i < A_ELEMS / 8; i += NTHR)
             reinterpret_cast<uint4*>(A_lds)[i] = make_uint4(0, 0, 0, 0);
-    }
-    if (pro) {
-        // GroupNorm statistics of the input: group = 16 channels x 64 squares
-        const int ngrp = Cin / 16;
-        const int board0 = m0 / 64;
-        for (int i = tid; i < 4 * ngrp; i += NTHR) {
-            int b = i / ngrp, g = i % ngrp;
-            const float* st = a.in_stats + ((size_t)(board0 + b) * Cin + g * 16) * 2;
-            float s = 0.f, ss = 0.f;
-            for (int c = 0; c < 16; ++c) { s += st[2 * c]; ss += st[2 * c + 1]; }
-            float mean = s * (1.f / 1024.f);
-            float var = ss * (1.f / 1024.f) - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            gstat[2 * i] = mean;
-            gstat[2 * i + 1] = rsqrtf(var + 1e-5f);
-        }
     }
     __syncthreads();
 
@@ -148,18 +132,6 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
                 int row = p / K8, c8 = p % K8;
                 int b = row >> 6, px = row & 63;
                 uint4 v = areg[i];
-                if (pro) {
-                    int c = chunk * KC + c8 * 8;
-                    const float mean = gstat[2 * (b * (Cin / 16) + (c >> 4))];
-                    const float rstd = gstat[2 * (b * (Cin / 16) + (c >> 4)) + 1];
-                    _Float16* h = reinterpret_cast<_Float16*>(&v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float x = (float)h[j];
-                        float y = (x - mean) * rstd * a.gamma[c + j] + a.beta[c + j];
-                        h[j] = (_Float16)act_apply(y, a.pro_act);
-                    }
-                }
                 int pix = (TAPS == 9) ? (b * 100 + ((px >> 3) + 1) * 10 + (px & 7) + 1) : row;
                 *reinterpret_cast<uint4*>(A_lds + pix * AST + c8 * 8) = v;
             }
@@ -260,12 +232,217 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     });
 }
 
+
+// ---------------------------------------------------------------------------
+// conv_big: the hot kernel (see file header)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 (hardware); the global source is per lane
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
+    constexpr int NT = 5;
+    constexpr int A_BYTES = 256 * 128;    // 4 boards x 64 squares x 64 channels fp16
+    constexpr int W_BYTES = 320 * 128;    // 320 output channels x 64 k fp16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A_lds = smem;                   // [2][A_BYTES]
+    char* W_lds = smem + 2 * A_BYTES;     // [2][W_BYTES]
+    char* Z_lds = W_lds + 2 * W_BYTES;    // one all-zero square (128 B)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3;              // board within the tile
+    const int wn = wave >> 2;             // N half (160 channels = 10 GroupNorm groups)
+    const int m0 = blockIdx.x * 256;
+    const int n0 = blockIdx.y * 320;
+    const int Cin = a.Cin;
+    const int nchunk = Cin >> 6;
+    const int nsteps = nchunk * TAPS;
+    const int half = lane >> 5;
+
+    if (tid < 8) reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);
+
+    const char* in_bytes = reinterpret_cast<const char*>(a.in);
+    const char* w_bytes = reinterpret_cast<const char*>(a.w);
+
+    auto issue_A = [&](int chunk, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave * 4 + i;                 // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
+            const int p = 8 * q + (lane >> 3);
+            const int cl = lane & 7;                    // LDS 16-byte chunk this lane fills
+            const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
+            glds16(src, A_lds + buf * A_BYTES + q * 1024);
+        }
+    };
+    auto issue_W = [&](int step, int buf) {
+        const int chunk = step / TAPS, tap = step - chunk * TAPS;
+        const char* src = w_bytes + ((size_t)(tap * nchunk + chunk) * a.Npad + n0) * 128;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wave * 5 + i;
+            glds16(src + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
+        }
+    };
+
+    float16v acc[2][NT];
+    static_for<0, 2>([&](auto mi) {
+        static_for<0, NT>([&](auto ni) {
+            acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        });
+    });
+
+    // per-lane constants of the fragment reads
+    const int r31 = lane & 31;
+    const int wfx = ((r31 >> 1) & 7) ^ half;                           // weight rows: swizzle key ^ k-half
+    const int wrow_off = (wn * 160 + r31) * 128;
+    int prow[2], py[2], px[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        prow[mi] = wm * 64 + mi * 32 + r31;
+        py[mi] = (prow[mi] >> 3) & 7;
+        px[mi] = prow[mi] & 7;
+    }
+
+    issue_A(0, 0);
+    issue_W(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int chunk = s / TAPS, tap = s - chunk * TAPS;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage s have landed
+        __syncthreads();                                   // ... everyone's have; step s-1 reads are done
+        if (s + 1 < nsteps) {
+            issue_W(s + 1, (s + 1) & 1);
+            if (tap == TAPS - 1) issue_A(chunk + 1, (chunk + 1) & 1);
+        }
+        const int dy = (TAPS == 9) ? (tap / 3 - 1) : 0;
+        const int dx = (TAPS == 9) ? (tap - (tap / 3) * 3 - 1) : 0;
+        const char* Ab = A_lds + (chunk & 1) * A_BYTES;
+        const char* Wb = W_lds + (s & 1) * W_BYTES + wrow_off;
+        const char* abase[2];
+        int afx[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int yy = py[mi] + dy, xx = px[mi] + dx;
+            const bool ok = (TAPS == 1) || ((unsigned)yy < 8u && (unsigned)xx < 8u);
+            const int pp = prow[mi] + dy * 8 + dx;
+            abase[mi] = ok ? Ab + pp * 128 : Z_lds;
+            afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
+        }
+        static_for<0, 4>([&](auto kk_) {
+            constexpr int kk = decltype(kk_)::value;
+            const half8 af0 = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
+            const half8 af1 = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
+            const int woff = 16 * (wfx ^ (kk << 1));
+            static_for<0, NT>([&](auto ni_) {
+                constexpr int ni = decltype(ni_)::value;
+                const half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf, acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf, acc[1][ni], 0, 0, 0);
+            });
+        });
+    }
+
+    // ---------------- epilogue ----------------
+    const int ldo = a.ldo;
+    const int rowbase = m0 + wm * 64 + 4 * half;
+    const int colbase = n0 + wn * 160 + r31;
+    if (a.gn_gamma != nullptr) {
+        // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
+        const int act = a.epi_act;
+        static_for<0, NT>([&](auto ni_) {
+            constexpr int ni = decltype(ni_)::value;
+            const int col = colbase + ni * 32;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 2>([&](auto mi_) {
+                const float16v av = acc[decltype(mi_)::value][ni];
+                static_for<0, 16>([&](auto r_) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+            });
+#pragma unroll
+            for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            const float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
+            const float sh = a.gn_beta[col] - mean * g;
+            static_for<0, 2>([&](auto mi_) {
+                constexpr int mi = decltype(mi_)::value;
+                const float16v av = acc[mi][ni];
+                static_for<0, 16>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = act_apply(av[r] * g + sh, act);
+                    if (row < a.Mvalid) reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
+                });
+            });
+        });
+        return;
+    }
+    const int epi_act = a.epi_act;
+    const float oscale = a.out_scale;
+    const bool has_mul = a.mul != nullptr;
+    const bool f32out = a.out_f32 != 0;
+    const bool want_stats = a.out_stats != nullptr;
+    static_for<0, NT>([&](auto ni_) {
+        constexpr int ni = decltype(ni_)::value;
+        const int col = colbase + ni * 32;
+        const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
+        float s = 0.f, ss = 0.f;
+        static_for<0, 2>([&](auto mi_) {
+            constexpr int mi = decltype(mi_)::value;
+            const float16v av = acc[mi][ni];
+            static_for<0, 16>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                float v = av[r] + bias;
+                if (epi_act != ACT_NONE) v = act_apply(v, epi_act);
+                if (has_mul) v *= (float)a.mul[(size_t)row * ldo + col];
+                v *= oscale;
+                s += v; ss += v * v;
+                if (row < a.Mvalid) {
+                    if (f32out) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
+                    else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
+                }
+            });
+        });
+        if (want_stats) {
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            if (lane < 32) {
+                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * a.N + col) * 2;
+                st[0] = s; st[1] = ss;
+            }
+        }
+    });
+}
+
+template <int TAPS>
+static hipError_t launch_conv_big_t(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 2 * 256 * 128 + 2 * 320 * 128 + 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(a.Mrows / 256, a.Npad / 320);
+    hipLaunchKernelGGL((conv_big_kernel<TAPS>), grid, dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int TAPS, int WN, int NT, int KC>
 static size_t conv_gemm_lds(int Cin) {
     constexpr int NB = WN * NT * 32;
     constexpr int AST = KC + 8;
     constexpr int APIX = (TAPS == 9) ? 100 : 64;
-    return (size_t)(4 * APIX * AST + 2 * NB * AST) * 2 + (size_t)4 * (Cin / 16) * 2 * 4 + 64;
+    (void)Cin;
+    return (size_t)(4 * APIX * AST + 2 * NB * AST) * 2 + 64;
 }
 
 template <int TAPS, int WN, int NT, int KC>
@@ -294,65 +471,79 @@ int conv_gemm_kc(int Cin, int Npad) {
 hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     if (a.Mrows % 256 != 0 || a.Cin % 32 != 0 || a.Npad % 32 != 0) return hipErrorInvalidValue;
     const bool big = conv_gemm_tile_n(a.Cin, a.Npad) == 320;
+    if (a.gn_gamma != nullptr && !big) return hipErrorInvalidValue;   // fused GN epilogue: big tile only
     if (taps == 9) {
-        if (big) return launch_conv_gemm_t<9, 2, 5, 64>(a, st);
+        if (big) return launch_conv_big_t<9>(a, st);
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
     } else if (taps == 1) {
-        if (big) return launch_conv_gemm_t<1, 2, 5, 64>(a, st);
+        if (big) return launch_conv_big_t<1>(a, st);
         return launch_conv_gemm_t<1, 1, 1, 32>(a, st);
     }
     return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------
-// ew_board: one workgroup (256 threads) per board, tensor [64][C] fp16.
+// ew_board: one workgroup (256 threads) per board, tensor [64][C] fp16, the board held in registers.
 //   v = t
-//   if t_stats:  v = act(GroupNorm16(v))             (gamma/beta, act)
-//   if se_w1:    v *= gate[c]   gate = sigmoid(W2 act(W1 pool + b1) + b2), pool from t_stats sums
+//   if gn_gamma: v = act(GroupNorm16(v))             (statistics from t_stats)
+//   elif se_w1:  v *= gate[c]   gate = sigmoid(W2 act(W1 pool + b1) + b2), pool from t_stats sums
 //   if res:      v += res
 //   if posenc:   v += posenc[n][c]
 //   if ln_g:     v = LayerNorm_C(v)
-//   y = v ; out_stats = per-channel (sum, sumsq) over the 64 squares
+//   y = v                                             (the raw residual stream)
+//   out_stats = per-channel (sum, sumsq) of y over the 64 squares
+//   if y2: y2 = act(GroupNorm16(y; gn2_gamma, gn2_beta))   -- the pre-activation input of the next block's conv1
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ew_board_kernel(EwArgs a) {
+__global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
+    // 8 waves; wave w owns squares w, w+8, ... (8 squares); lane l < C/8 owns channels 8l..8l+7 of each
+    // (one 16-byte load/store per square).  Memory-bound: ~4 x 40 KB per board at C = 320.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = a.C;
-    float* sc = reinterpret_cast<float*>(smem);        // [C] scale (GN) or gate (SE)
-    float* sh = sc + C;                                // [C] shift
-    float* red = sh + C;                               // [4 waves][C][2] stats partials
-    float* hid = red + 4 * C * 2;                      // [hidden]
+    float* sc = reinterpret_cast<float*>(smem);        // [C] scale (GN) or gate (SE); later GN2 scale
+    float* sh = sc + C;                                // [C] shift / pooled mean
+    float* red = sh + C;                               // [8 waves][C][2] stats partials (also SE partials)
+    float* tot = red + 8 * C * 2;                      // [C][2]
+    float* hid = tot + 2 * C;                          // [hidden]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const _Float16* t = a.t + (size_t)b * 64 * C;
     const float* tst = a.t_stats ? a.t_stats + (size_t)b * C * 2 : nullptr;
 
     if (a.gn_gamma != nullptr) {
-        for (int c = tid; c < C; c += 256) {
-            int g0 = (c >> 4) << 4;
+        for (int c = tid; c < C; c += 512) {
+            const int g0 = (c >> 4) << 4;
             float s = 0.f, ss = 0.f;
             for (int j = 0; j < 16; ++j) { s += tst[2 * (g0 + j)]; ss += tst[2 * (g0 + j) + 1]; }
-            float mean = s * (1.f / 1024.f);
+            const float mean = s * (1.f / 1024.f);
             float var = ss * (1.f / 1024.f) - mean * mean;
             var = var > 0.f ? var : 0.f;
-            float rstd = rsqrtf(var + 1e-5f);
-            float g = a.gn_gamma[c] * rstd;
+            const float g = a.gn_gamma[c] * rsqrtf(var + 1e-5f);
             sc[c] = g;
             sh[c] = a.gn_beta[c] - mean * g;
         }
     } else if (a.se_w1 != nullptr) {
         // squeeze-excite gate (resnet.py:59-68); pooled mean from the conv epilogue sums
-        for (int c = tid; c < C; c += 256) sh[c] = tst[2 * c] * (1.f / 64.f);
-        __syncthreads();
         const int Hd = a.se_hidden;
-        for (int j = tid; j < Hd; j += 256) {
+        for (int c = tid; c < C; c += 512) sh[c] = tst[2 * c] * (1.f / 64.f);
+        __syncthreads();
+        // hidden = act(W1 pool + b1): wave w sums channels [w*C/8, (w+1)*C/8), lanes over hidden units
+        const int cs = (C + 7) / 8;
+        for (int j = lane; j < Hd; j += 64) {
+            float s = 0.f;
+            const int c1 = (wave + 1) * cs < C ? (wave + 1) * cs : C;
+            for (int c = wave * cs; c < c1; ++c) s += a.se_w1[(size_t)c * Hd + j] * sh[c];   // w1 stored [C][Hd]
+            red[wave * Hd + j] = s;
+        }
+        __syncthreads();
+        for (int j = tid; j < Hd; j += 512) {
             float s = a.se_b1[j];
-            for (int c = 0; c < C; ++c) s += a.se_w1[(size_t)c * Hd + j] * sh[c];   // w1 stored [C][Hd]
+            for (int w = 0; w < 8; ++w) s += red[w * Hd + j];
             hid[j] = act_apply(s, a.act);
         }
         __syncthreads();
-        for (int c = tid; c < C; c += 256) {
+        for (int c = tid; c < C; c += 512) {
             float s = a.se_b2[c];
-            for (int j = 0; j < Hd; ++j) s += a.se_w2[(size_t)c * Hd + j] * hid[j];
+            for (int j = 0; j < Hd; ++j) s += a.se_w2[(size_t)j * C + c] * hid[j];          // w2 stored [Hd][C]
             sc[c] = 1.f / (1.f + __expf(-s));
         }
     }
@@ -362,69 +553,108 @@ __global__ __launch_bounds__(256) void ew_board_kernel(EwArgs a) {
     const bool se = (!gn) && a.se_w1 != nullptr;
     const _Float16* res = a.res ? a.res + (size_t)b * 64 * C : nullptr;
     _Float16* y = a.y + (size_t)b * 64 * C;
-    const int nper = (C + 63) / 64;      // channels per lane (strided by 64), <= 8
+    const int c0 = lane * 8;
+    const bool live = c0 < C;
     float csum[8], csq[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { csum[i] = 0.f; csq[i] = 0.f; }
-    for (int n = wave; n < 64; n += 4) {
-        float v[8];
+    static_for<0, 8>([&](auto i_) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+    float scl[8], shl[8];
+    static_for<0, 8>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        scl[i] = (live && (gn || se)) ? sc[c0 + i] : 1.f;
+        shl[i] = (live && gn) ? sh[c0 + i] : 0.f;
+    });
+    for (int k = 0; k < 8; ++k) {
+        const int n = wave + 8 * k;
         float rs = 0.f, rss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int c = lane + 64 * i;
-            v[i] = 0.f;
-            if (i < nper && c < C) {
-                float x = (float)t[n * C + c];
-                if (gn) x = act_apply(x * sc[c] + sh[c], a.act);
-                else if (se) x *= sc[c];
-                if (res) x += (float)res[n * C + c];
-                if (a.posenc) x += a.posenc[n * C + c];
-                v[i] = x; rs += x; rss += x * x;
-            }
+        half8 tv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            tv = *reinterpret_cast<const half8*>(t + n * C + c0);
+            if (res) rv = *reinterpret_cast<const half8*>(res + n * C + c0);
         }
+        float v[8];
+        static_for<0, 8>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            float x = (float)tv[i];
+            if (gn) x = act_apply(x * scl[i] + shl[i], a.act);
+            else if (se) x *= scl[i];
+            x += (float)rv[i];
+            if (a.posenc && live) x += a.posenc[n * C + c0 + i];
+            if (!live) x = 0.f;
+            v[i] = x; rs += x; rss += x * x;
+        });
         if (a.ln_g != nullptr) {
             for (int o = 32; o > 0; o >>= 1) { rs += __shfl_xor(rs, o); rss += __shfl_xor(rss, o); }
-            float mean = rs / (float)C;
+            const float mean = rs / (float)C;
             float var = rss / (float)C - mean * mean;
             var = var > 0.f ? var : 0.f;
-            float rstd = rsqrtf(var + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int c = lane + 64 * i;
-                if (i < nper && c < C) v[i] = (v[i] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
-            }
+            const float rstd = rsqrtf(var + 1e-5f);
+            static_for<0, 8>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                if (live) v[i] = (v[i] - mean) * rstd * a.ln_g[c0 + i] + a.ln_b[c0 + i];
+            });
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int c = lane + 64 * i;
-            if (i < nper && c < C) {
-                _Float16 h = (_Float16)v[i];
-                y[n * C + c] = h;
-                float q = a.stats_from_rounded ? (float)h : v[i];
-                csum[i] += q; csq[i] += q * q;
-            }
-        }
+        half8 ov;
+        static_for<0, 8>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            ov[i] = (_Float16)v[i];
+            csum[i] += v[i]; csq[i] += v[i] * v[i];
+        });
+        if (live) *reinterpret_cast<half8*>(y + n * C + c0) = ov;
     }
-    if (a.out_stats != nullptr) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int c = lane + 64 * i;
-            if (i < nper && c < C) { red[(wave * C + c) * 2] = csum[i]; red[(wave * C + c) * 2 + 1] = csq[i]; }
-        }
-        __syncthreads();
-        for (int c = tid; c < C; c += 256) {
-            float s = 0.f, ss = 0.f;
-            for (int w = 0; w < 4; ++w) { s += red[(w * C + c) * 2]; ss += red[(w * C + c) * 2 + 1]; }
+    if (a.out_stats == nullptr && a.y2 == nullptr) return;
+    if (live) {
+        static_for<0, 8>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            red[(wave * C + c0 + i) * 2] = csum[i]; red[(wave * C + c0 + i) * 2 + 1] = csq[i];
+        });
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 512) {
+        float s = 0.f, ss = 0.f;
+        for (int w = 0; w < 8; ++w) { s += red[(w * C + c) * 2]; ss += red[(w * C + c) * 2 + 1]; }
+        tot[2 * c] = s; tot[2 * c + 1] = ss;
+        if (a.out_stats != nullptr) {
             a.out_stats[((size_t)b * C + c) * 2] = s;
             a.out_stats[((size_t)b * C + c) * 2 + 1] = ss;
         }
     }
+    if (a.y2 == nullptr) return;
+    __syncthreads();
+    for (int c = tid; c < C; c += 512) {
+        const int g0 = (c >> 4) << 4;
+        float s = 0.f, ss = 0.f;
+        for (int j = 0; j < 16; ++j) { s += tot[2 * (g0 + j)]; ss += tot[2 * (g0 + j) + 1]; }
+        const float mean = s * (1.f / 1024.f);
+        float var = ss * (1.f / 1024.f) - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float g = a.gn2_gamma[c] * rsqrtf(var + 1e-5f);
+        sc[c] = g;
+        sh[c] = a.gn2_beta[c] - mean * g;
+    }
+    __syncthreads();
+    if (!live) return;
+    _Float16* y2 = a.y2 + (size_t)b * 64 * C;
+    static_for<0, 8>([&](auto i_) { constexpr int i = decltype(i_)::value; scl[i] = sc[c0 + i]; shl[i] = sh[c0 + i]; });
+    // second output from the values this very thread has just stored (L2-hot; keeps the kernel at ~50 VGPRs so
+    // several boards overlap per CU instead of holding the whole board in registers)
+    for (int k = 0; k < 8; ++k) {
+        const int n = wave + 8 * k;
+        const half8 yv = *reinterpret_cast<const half8*>(y + n * C + c0);
+        half8 ov;
+        static_for<0, 8>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            ov[i] = (_Float16)act_apply((float)yv[i] * scl[i] + shl[i], a.act);
+        });
+        *reinterpret_cast<half8*>(y2 + n * C + c0) = ov;
+    }
 }
 
 hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st) {
-    if (a.C > 512) return hipErrorInvalidValue;
-    size_t lds = (size_t)(2 * a.C + 8 * a.C + (a.se_hidden > 0 ? a.se_hidden : 1)) * 4;
-    hipLaunchKernelGGL(ew_board_kernel, dim3(boards), dim3(256), lds, st, a);
+    if (a.C > 512 || a.C % 8 != 0) return hipErrorInvalidValue;
+    const int hd = a.se_hidden > 0 ? a.se_hidden : 1;
+    size_t redsz = (size_t)16 * a.C > (size_t)8 * hd ? (size_t)16 * a.C : (size_t)8 * hd;
+    size_t lds = (size_t)(2 * a.C + redsz + 2 * a.C + hd) * 4;
+    hipLaunchKernelGGL(ew_board_kernel, dim3(boards), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
