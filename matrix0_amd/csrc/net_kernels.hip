@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     __syncthreads();
 
     float16v acc[2][NT];
-    static_for<0, 2>([&](auto mi) {
-        static_for<0, NT>([&](auto ni) {
+    static_for<0, 2>([&](auto mi) __attribute__((always_inline)) {
+        static_for<0, NT>([&](auto ni) __attribute__((always_inline)) {
             acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                                       0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         });
@@ -176,11 +176,11 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
         }
         const int tapoff = (TAPS == 9) ? ((tap / 3 - 1) * 10 + (tap % 3 - 1)) : 0;
         const _Float16* Wb = W_lds + (s & 1) * W_ELEMS + (wn * NT * 32 + (lane & 31)) * AST + khalf;
-        static_for<0, KC / 16>([&](auto kk_) {
+        static_for<0, KC / 16>([&](auto kk_) __attribute__((always_inline)) {
             constexpr int kk = decltype(kk_)::value;
             half8 af0 = *reinterpret_cast<const half8*>(A_lds + (apix[0] + tapoff) * AST + kk * 16 + khalf);
             half8 af1 = *reinterpret_cast<const half8*>(A_lds + (apix[1] + tapoff) * AST + kk * 16 + khalf);
-            static_for<0, NT>([&](auto ni_) {
+            static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
                 constexpr int ni = decltype(ni_)::value;
                 half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 32 * AST + kk * 16);
                 acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf, acc[0][ni], 0, 0, 0);
@@ -199,15 +199,15 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     const bool has_mul = a.mul != nullptr;
     const bool f32out = a.out_f32 != 0;
     const bool want_stats = a.out_stats != nullptr;
-    static_for<0, NT>([&](auto ni_) {
+    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
         constexpr int ni = decltype(ni_)::value;
         const int col = colbase + ni * 32;
         const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
         float s = 0.f, ss = 0.f;
-        static_for<0, 2>([&](auto mi_) {
+        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
             constexpr int mi = decltype(mi_)::value;
             const float16v av = acc[mi][ni];
-            static_for<0, 16>([&](auto r_) {
+            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
                 const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
                 float v = av[r] + bias;
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     };
 
     float16v acc[2][NT];
-    static_for<0, 2>([&](auto mi) {
-        static_for<0, NT>([&](auto ni) {
+    static_for<0, 2>([&](auto mi) __attribute__((always_inline)) {
+        static_for<0, NT>([&](auto ni) __attribute__((always_inline)) {
             acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                                       0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         });
@@ -333,12 +333,12 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
             abase[mi] = ok ? Ab + pp * 128 : Z_lds;
             afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
         }
-        static_for<0, 4>([&](auto kk_) {
+        static_for<0, 4>([&](auto kk_) __attribute__((always_inline)) {
             constexpr int kk = decltype(kk_)::value;
             const half8 af0 = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
             const half8 af1 = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
             const int woff = 16 * (wfx ^ (kk << 1));
-            static_for<0, NT>([&](auto ni_) {
+            static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
                 constexpr int ni = decltype(ni_)::value;
                 const half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
                 acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf, acc[0][ni], 0, 0, 0);
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     if (a.gn_gamma != nullptr) {
         // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
         const int act = a.epi_act;
-        static_for<0, NT>([&](auto ni_) {
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
             constexpr int ni = decltype(ni_)::value;
             const int col = colbase + ni * 32;
             float s = 0.f, ss = 0.f;
-            static_for<0, 2>([&](auto mi_) {
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
                 const float16v av = acc[decltype(mi_)::value][ni];
-                static_for<0, 16>([&](auto r_) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
             });
 #pragma unroll
             for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
             var = var > 0.f ? var : 0.f;
             const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
             const float sh = a.gn_beta[col] - mean * g;
-            static_for<0, 2>([&](auto mi_) {
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
                 constexpr int mi = decltype(mi_)::value;
                 const float16v av = acc[mi][ni];
-                static_for<0, 16>([&](auto r_) {
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
                     const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
                     const float v = act_apply(av[r] * g + sh, act);
@@ -388,15 +388,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     const bool has_mul = a.mul != nullptr;
     const bool f32out = a.out_f32 != 0;
     const bool want_stats = a.out_stats != nullptr;
-    static_for<0, NT>([&](auto ni_) {
+    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
         constexpr int ni = decltype(ni_)::value;
         const int col = colbase + ni * 32;
         const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
         float s = 0.f, ss = 0.f;
-        static_for<0, 2>([&](auto mi_) {
+        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
             constexpr int mi = decltype(mi_)::value;
             const float16v av = acc[mi][ni];
-            static_for<0, 16>([&](auto r_) {
+            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
                 const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
                 float v = av[r] + bias;
@@ -556,9 +556,9 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
     const int c0 = lane * 8;
     const bool live = c0 < C;
     float csum[8], csq[8];
-    static_for<0, 8>([&](auto i_) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
     float scl[8], shl[8];
-    static_for<0, 8>([&](auto i_) {
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
         scl[i] = (live && (gn || se)) ? sc[c0 + i] : 1.f;
         shl[i] = (live && gn) ? sh[c0 + i] : 0.f;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
             if (res) rv = *reinterpret_cast<const half8*>(res + n * C + c0);
         }
         float v[8];
-        static_for<0, 8>([&](auto i_) {
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
             float x = (float)tv[i];
             if (gn) x = act_apply(x * scl[i] + shl[i], a.act);
@@ -588,13 +588,13 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
             float var = rss / (float)C - mean * mean;
             var = var > 0.f ? var : 0.f;
             const float rstd = rsqrtf(var + 1e-5f);
-            static_for<0, 8>([&](auto i_) {
+            static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_)::value;
                 if (live) v[i] = (v[i] - mean) * rstd * a.ln_g[c0 + i] + a.ln_b[c0 + i];
             });
         }
         half8 ov;
-        static_for<0, 8>([&](auto i_) {
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
             ov[i] = (_Float16)v[i];
             csum[i] += v[i]; csq[i] += v[i] * v[i];
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
     }
     if (a.out_stats == nullptr && a.y2 == nullptr) return;
     if (live) {
-        static_for<0, 8>([&](auto i_) {
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
             red[(wave * C + c0 + i) * 2] = csum[i]; red[(wave * C + c0 + i) * 2 + 1] = csq[i];
         });
@@ -634,14 +634,14 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
     __syncthreads();
     if (!live) return;
     _Float16* y2 = a.y2 + (size_t)b * 64 * C;
-    static_for<0, 8>([&](auto i_) { constexpr int i = decltype(i_)::value; scl[i] = sc[c0 + i]; shl[i] = sh[c0 + i]; });
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { constexpr int i = decltype(i_)::value; scl[i] = sc[c0 + i]; shl[i] = sh[c0 + i]; });
     // second output from the values this very thread has just stored (L2-hot; keeps the kernel at ~50 VGPRs so
     // several boards overlap per CU instead of holding the whole board in registers)
     for (int k = 0; k < 8; ++k) {
         const int n = wave + 8 * k;
         const half8 yv = *reinterpret_cast<const half8*>(y + n * C + c0);
         half8 ov;
-        static_for<0, 8>([&](auto i_) {
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
             ov[i] = (_Float16)act_apply((float)yv[i] * scl[i] + shl[i], a.act);
         });
@@ -666,9 +666,11 @@ hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st) {
 //   mix >= 1: masked only ; mix <= 0: unmasked only.
 // o [B][64][C] fp16 with channel h*D+d.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
-    __shared__ float Ks[4][64][17];
-    __shared__ float Vs[4][64][17];
+__global__ __launch_bounds__(256, 4) void attn_core_kernel(AttnArgs a) {
+    // One wave per (board, head).  S^T = K Q^T on MFMA (32x32x16, K = head_dim = 16: one MFMA per 32x32 tile,
+    // operands straight from global memory), so a lane owns one query (column) and its keys sit in registers:
+    // the softmax sums over keys need a single cross-half shuffle.  PV on the VALU with V rows broadcast from LDS.
+    __shared__ __attribute__((aligned(16))) float Vs[4][64][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, C = a.C;
     const long job = (long)blockIdx.x * 4 + wave;
@@ -676,54 +678,92 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
     const bool live = job < njobs;
     const int b = live ? (int)(job / H) : 0, h = live ? (int)(job % H) : 0;
     const _Float16* base = a.qkv + (size_t)b * 64 * 3 * C;
-    float q[16];
-    {
-        const _Float16* qp = base + (size_t)lane * 3 * C + (0 * H + h) * 16;
-        const _Float16* kp = base + (size_t)lane * 3 * C + (1 * H + h) * 16;
+    const int r31 = lane & 31, half = lane >> 5;
+    {   // V row `lane` -> LDS as fp32
         const _Float16* vp = base + (size_t)lane * 3 * C + (2 * H + h) * 16;
+        const half8 v0 = *reinterpret_cast<const half8*>(vp), v1 = *reinterpret_cast<const half8*>(vp + 8);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            q[d] = (float)qp[d];
-            Ks[wave][lane][d] = (float)kp[d];
-            Vs[wave][lane][d] = (float)vp[d];
-        }
+        for (int d = 0; d < 8; ++d) { Vs[wave][lane][d] = (float)v0[d]; Vs[wave][lane][8 + d] = (float)v1[d]; }
     }
+    // MFMA operands: A = K (rows = keys), B = Q^T (cols = queries); lane holds 8 consecutive head dims
+    half8 kf[2], qf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        kf[t] = *reinterpret_cast<const half8*>(base + (size_t)(t * 32 + r31) * 3 * C + (1 * H + h) * 16 + 8 * half);
+        qf[t] = *reinterpret_cast<const half8*>(base + (size_t)(t * 32 + r31) * 3 * C + (0 * H + h) * 16 + 8 * half);
+    }
+    const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    const uint64_t mrow = a.mask[lane];
-    const float* rb = a.rel_bias ? a.rel_bias + ((size_t)h * 64 + lane) * 64 : nullptr;
-    // Scores are clamped to [-50,50], so exp() needs no max subtraction in fp32, and the
-    // masked branch's -1e4 fill underflows to exactly 0 (the query's own square is always
-    // visible, so the masked row maximum is >= -50): e_masked = visible ? e : 0.
-    float su = 0.f, sm = 0.f;
-    float ou[16], om[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) { ou[d] = 0.f; om[d] = 0.f; }
-#pragma unroll 4
-    for (int j = 0; j < 64; ++j) {
-        float d = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d += q[k] * Ks[wave][j][k];
-        d *= a.inv_sqrt_d;
-        if (rb) d += rb[j];
-        d = fminf(fmaxf(d, -50.f), 50.f);
-        const float eu = __expf(d);
-        const float em = ((mrow >> j) & 1ull) ? eu : 0.f;
-        su += eu; sm += em;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float v = Vs[wave][j][k];
-            ou[k] += eu * v; om[k] += em * v;
+    float wm_, wu_;   // output weights of the masked / unmasked branch (resnet.py:154-174)
+    if (a.mix > 0.f && a.mix < 1.f) { wm_ = 1.f - a.mix; wu_ = 1.f - (1.f - a.mix); }
+    else if (a.mix >= 1.f) { wm_ = 1.f; wu_ = 0.f; }
+    else { wm_ = 0.f; wu_ = 1.f; }
+    const float isd = a.inv_sqrt_d;
+    static_for<0, 2>([&](auto qt_) __attribute__((always_inline)) {
+        constexpr int qt = decltype(qt_)::value;
+        const int q = qt * 32 + r31;
+        // S^T tiles for this query tile: row (key) = (r&3)+8*(r>>2)+4*half (+32 for the 2nd), col (query) = lane&31
+        float16v st[2];
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qt], zero, 0, 0, 0);
+        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[qt], zero, 0, 0, 0);
+        const uint64_t mrow = a.mask[q];
+        const float* rb = a.rel_bias ? a.rel_bias + ((size_t)h * 64 + q) * 64 : nullptr;
+        // scores clamped to [-50,50]: exp needs no max subtraction; masked fill -1e4 underflows to exactly 0
+        float e[2][16];
+        float su = 0.f, sm = 0.f;
+        static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_)::value;
+            static_for<0, 4>([&](auto g_) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_)::value;
+                const int key0 = kt * 32 + 8 * g + 4 * half;
+                float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rb) bias = *reinterpret_cast<const float4*>(rb + key0);
+                const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_)::value;
+                    float d = st[kt][4 * g + j] * isd + bb[j];
+                    d = fminf(fmaxf(d, -50.f), 50.f);
+                    const float eu = __expf(d);
+                    e[kt][4 * g + j] = eu;
+                    su += eu;
+                    sm += ((mrow >> (key0 + j)) & 1ull) ? eu : 0.f;
+                });
+            });
+        });
+        su += __shfl_xor(su, 32);
+        sm += __shfl_xor(sm, 32);
+        const float cu = wu_ / su, cm = wm_ / sm;
+        float o[16];
+        static_for<0, 16>([&](auto d_) __attribute__((always_inline)) { o[decltype(d_)::value] = 0.f; });
+        static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_)::value;
+            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_)::value;
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float p = e[kt][r] * (cu + (((mrow >> key) & 1ull) ? cm : 0.f));
+                // keep the V-row loads of different keys from being hoisted together (512 VGPRs + spills otherwise)
+                if ((r & 1) == 0) asm volatile("" ::: "memory");
+                const float4* vr = reinterpret_cast<const float4*>(&Vs[wave][key][0]);
+                const float4 v0 = vr[0], v1 = vr[1], v2 = vr[2], v3 = vr[3];
+                o[0] += p * v0.x; o[1] += p * v0.y; o[2] += p * v0.z; o[3] += p * v0.w;
+                o[4] += p * v1.x; o[5] += p * v1.y; o[6] += p * v1.z; o[7] += p * v1.w;
+                o[8] += p * v2.x; o[9] += p * v2.y; o[10] += p * v2.z; o[11] += p * v2.w;
+                o[12] += p * v3.x; o[13] += p * v3.y; o[14] += p * v3.z; o[15] += p * v3.w;
+            });
+        });
+        half8 o0, o1;
+        static_for<0, 8>([&](auto d_) __attribute__((always_inline)) {
+            constexpr int d = decltype(d_)::value;
+            const float x0 = o[d] + __shfl_xor(o[d], 32);
+            const float x1 = o[8 + d] + __shfl_xor(o[8 + d], 32);
+            o0[d] = (_Float16)x0; o1[d] = (_Float16)x1;
+        });
+        if (live) {
+            _Float16* op = a.o + ((size_t)b * 64 + q) * C + h * 16;
+            if (half == 0) *reinterpret_cast<half8*>(op) = o0;
+            else *reinterpret_cast<half8*>(op + 8) = o1;
         }
-    }
-    if (live) {
-        float wu, wmk;
-        if (a.mix > 0.f && a.mix < 1.f) { wmk = (1.f - a.mix) / sm; wu = (1.f - (1.f - a.mix)) / su; }
-        else if (a.mix >= 1.f) { wmk = 1.f / sm; wu = 0.f; }
-        else { wmk = 0.f; wu = 1.f / su; }
-        _Float16* op = a.o + ((size_t)b * 64 + lane) * C + h * 16;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) op[d] = (_Float16)(wmk * om[d] + wu * ou[d]);
-    }
+    });
 }
 
 hipError_t launch_attn_core(const AttnArgs& a, hipStream_t st) {
