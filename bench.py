@@ -140,29 +140,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # weights: rank 0 synthesises, RCCL broadcast (the optional weight broadcast of the north star)
-    shapes = net_ref.param_shapes(R24_320)
-    if rank == 0:
-        sd = net_ref.random_state_dict(R24_320, seed=0)
+    from matrix0_amd import dist as m0dist
+    sd = net_ref.random_state_dict(R24_320, seed=0) if rank == 0 else None
     if distributed:
-        names = list(shapes.keys())
-        total = sum(int(np.prod(shapes[k])) if shapes[k] else 1 for k in names)
-        blob = torch.empty(total, dtype=torch.float32, device="cuda")
-        if rank == 0:
-            blob.copy_(torch.cat([sd[k].reshape(-1).float() for k in names]))
-        dist.broadcast(blob, src=0)
-        flat = blob.cpu()
-        sd, off = {}, 0
-        for k in names:
-            n = int(np.prod(shapes[k])) if shapes[k] else 1
-            sd[k] = flat[off:off + n].reshape(shapes[k])
-            off += n
+        sd = m0dist.broadcast_state_dict(sd, R24_320, src=0, device=torch.device("cuda", local_rank))
     be = M0Backend.from_state_dict(R24_320, sd, device_index=local_rank)
     flops_eval = be.flops_per_position(with_ssl=args.ssl)
 
     cfg_dict = json.loads(json.dumps(SELFPLAY_CFG))
     cfg_dict["selfplay"]["num_simulations"] = args.sims
     cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
-                                     first_game_index=rank * args.games, leaves_per_step=args.leaves,
+                                     first_game_index=m0dist.shard_games(args.games * world, rank, world)[0], leaves_per_step=args.leaves,
                                      virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
     e = eng.SelfplayEngine(be, cfg)
 
@@ -187,14 +175,10 @@ def main():
     be.profile_enable(False)
 
     d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total")}
-    vec = torch.tensor([dt, d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
-                        d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"]], dtype=torch.float64, device="cuda")
-    if distributed:
-        tmax = vec[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        vec[0] = tmax[0]
-    dt_max, evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims = [float(x) for x in vec.cpu()]
+    counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
+                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"]], dtype=np.float64)
+    dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
+    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims = [float(x) for x in tot]
 
     if rank == 0:
         ppg, basis_src = game_length_basis()

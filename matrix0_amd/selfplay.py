@@ -1,0 +1,104 @@
+"""Drop-in for the reference's worker entry
+
+    selfplay_worker(proc_id, cfg_dict, ckpt_path, games, q=None, shared_memory_resource=None)
+
+(azchess/selfplay/internal.py:94-95; started as Process(target=selfplay_worker, args=(i, sp_cfg, ckpt, games, q, sm_res))
+by orchestrator.py:494 and selfplay/__main__.py:68).  Same config dict, same queue messages
+(internal.py:542-556 heartbeat, 665-679 game), same NPZ shards and SQLite rows (internal.py:628-653).
+
+Instead of one game at a time with a Python MCTS, the games of this worker run concurrently on one MI355X inside
+libm0engine.so; `shared_memory_resource` (the reference's inference-server handle) is accepted and ignored: leaf
+batching happens in the engine.  New keys live under an `engine:` section only:
+    engine: {device_index: int, concurrent_games: int, leaves_per_step: int, virtual_loss_active: bool}
+"""
+from __future__ import annotations
+
+import logging
+import os
+import random
+import time
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import encoding
+from .backend import M0Backend
+from .data_writer import SelfplayShardWriter
+from .engine import SelfplayEngine, selfplay_cfg_from_dict
+from .weights import random_state_dict
+
+START_W = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+START_B = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR b KQkq - 0 1"
+
+
+def detect_value_from_white(backend: M0Backend) -> bool:
+    """selfplay/internal.py:203-238: same position with either side to move; side-to-move nets flip sign."""
+    planes, _, _ = encoding.encode_fens([START_W, START_B], want_moves=False)
+    _, v = backend.infer_np(planes)
+    v1, v2 = float(v[0]), float(v[1])
+    return not (abs(v2 + v1) < abs(v2 - v1))
+
+
+def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], games: int, q=None,
+                    shared_memory_resource: Optional[Dict[str, Any]] = None) -> None:
+    logger = logging.getLogger(f"selfplay_worker_{proc_id}")
+    base_seed = int(cfg_dict.get("seed", 1234))
+    random.seed(base_seed + proc_id)
+    np.random.seed(base_seed + proc_id)
+    eng_cfg = dict(cfg_dict.get("engine", {}) or {})
+    device_index = int(eng_cfg.get("device_index", 0))
+    model_cfg = dict(cfg_dict["model"])
+    if ckpt_path and os.path.exists(ckpt_path):
+        backend = M0Backend.from_checkpoint(model_cfg, ckpt_path, device_index)
+        logger.info("Loaded checkpoint from %s", ckpt_path)
+    else:
+        backend = M0Backend.from_state_dict(model_cfg, random_state_dict(model_cfg, seed=base_seed + proc_id), device_index)
+        logger.info("No checkpoint provided, using untrained model")
+    force_vfw = bool((cfg_dict.get("mcts", {}) or {}).get("value_from_white", False))
+    value_from_white = force_vfw or detect_value_from_white(backend)
+    cfg2 = dict(cfg_dict)
+    cfg2["mcts"] = dict(cfg_dict.get("mcts", {}) or {}, value_from_white=value_from_white)
+    concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
+    scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
+                                  first_game_index=0, seed=base_seed + proc_id,
+                                  leaves_per_step=eng_cfg.get("leaves_per_step", 16),
+                                  virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True)
+    engine = SelfplayEngine(backend, scfg)
+    writer = SelfplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"))
+    last_hb = time.perf_counter()
+    done = 0
+    try:
+        while engine.running():
+            engine.step(int(eng_cfg.get("steps_per_poll", 8)))
+            while True:
+                rec = engine.poll()
+                if rec is None:
+                    break
+                T = rec["moves"]
+                z = float(rec["result"])
+                game_data = {                                       # internal.py:628-646
+                    "s": rec["s"].astype(np.float32), "pi": rec["pi"].astype(np.float32), "z": rec["z"].astype(np.float32),
+                    "meta_moves": np.array([T], dtype=np.int32), "meta_result": np.array([z], dtype=np.float32),
+                    "meta_resigned": np.array([1 if rec["resigned"] else 0], dtype=np.int8),
+                    "meta_draw": np.array([1 if z == 0.0 else 0], dtype=np.int8),
+                    "meta_avg_policy_entropy": np.array([rec["avg_policy_entropy"]], dtype=np.float32),
+                    "meta_avg_sims": np.array([rec["avg_sims"]], dtype=np.float32),
+                    "legal_mask": rec["legal_mask"].astype(np.uint8),
+                }
+                filepath = writer.add_selfplay_data(game_data, worker_id=proc_id, game_id=rec["game_index"]) if T > 0 else None
+                done += 1
+                if q is not None:                                   # internal.py:665-679
+                    q.put({"type": "game", "proc": proc_id, "file": filepath, "moves": T, "result": z,
+                           "secs": rec["secs"], "resigned": rec["resigned"], "resigner": rec["resigner"],
+                           "draw": bool(z == 0.0), "avg_policy_entropy": rec["avg_policy_entropy"],
+                           "avg_ms_per_move": rec["secs"] * 1000.0 / max(1, T), "avg_sims": rec["avg_sims"]})
+            now = time.perf_counter()
+            if q is not None and now - last_hb >= 2.0:             # internal.py:542-556
+                st = engine.stats()
+                q.put({"type": "heartbeat", "proc": proc_id, "game": done, "moves": int(st["plies"]),
+                       "avg_sims": float(st["sims"]) / max(1.0, float(st["plies"])), "resigned": False,
+                       "avg_policy_entropy": 0.0})
+                last_hb = now
+    finally:
+        engine.close()
+        backend.close()

@@ -94,3 +94,34 @@ def test_selfplay_is_deterministic_for_a_seed():
         outs.append(games)
         e.close()
     assert outs[0] == outs[1]
+
+
+def test_drop_in_worker_writes_shards_and_queue_messages(tmp_path):
+    """selfplay_worker(proc_id, cfg_dict, ckpt_path, games, q): same call as the reference (internal.py:94-95);
+    checks the queue message schema (internal.py:665-679) and the NPZ/SQLite contract (internal.py:628-653)."""
+    import queue
+    import sqlite3
+    from matrix0_amd.selfplay import selfplay_worker
+    cfg = dict(CFG, model=NET, data_dir=str(tmp_path), engine={"concurrent_games": 3, "leaves_per_step": 8})
+    q = queue.Queue()
+    selfplay_worker(0, cfg, None, 4, q, None)
+    msgs = []
+    while not q.empty():
+        msgs.append(q.get())
+    games = [m for m in msgs if m["type"] == "game"]
+    assert len(games) == 4
+    want = {"type", "proc", "file", "moves", "result", "secs", "resigned", "resigner", "draw", "avg_policy_entropy",
+            "avg_ms_per_move", "avg_sims"}
+    for m in games:
+        assert set(m) == want and m["proc"] == 0
+        z = np.load(m["file"])
+        T = m["moves"]
+        assert z["s"].shape == (T, 19, 8, 8) and z["s"].dtype == np.float32
+        assert z["pi"].shape == (T, 4672) and z["pi"].dtype == np.float32 and z["z"].shape == (T,)
+        assert z["legal_mask"].shape == (T, 4672) and z["legal_mask"].dtype == np.uint8
+        assert z["meta_moves"].dtype == np.int32 and int(z["meta_moves"][0]) == T
+        assert z["meta_result"].dtype == np.float32 and z["meta_resigned"].dtype == np.int8 and z["meta_draw"].dtype == np.int8
+        assert z["meta_avg_policy_entropy"].dtype == np.float32 and z["meta_avg_sims"].dtype == np.float32
+        np.testing.assert_allclose(z["pi"].sum(axis=1), 1.0, atol=1e-3)
+    n = sqlite3.connect(str(tmp_path / "data_metadata.db")).execute("SELECT count(*), sum(sample_count) FROM shards").fetchone()
+    assert n[0] == 4 and n[1] == sum(m["moves"] for m in games)
