@@ -110,6 +110,9 @@ int m0_net_profile_get(m0_net* net, double* conv_ms, double* conv_flop, int64_t*
  *   moves u16 [n,256] (from | to<<6 | promo<<12, promo 1..4 = N,B,R,Q) in legal_moves order; idx i32 [n,256]. */
 int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes, uint8_t* mask, int32_t* nlegal,
                    uint16_t* moves, int32_t* idx);
+/* ChessSSLAlgorithms.create_enhanced_ssl_targets (azchess/ssl_algorithms.py:519-543) on the device:
+ * out f32 [n,17,8,8] = piece one-hot (13) | threat | pin | fork | control, tensor orientation. */
+int m0_ssl_targets_fens(int hip_device, const char* const* fens, int n, float* out);
 /* move_to_index for one (fen, uci): raises M0_ERR_INVALID for an illegal move (ValueError in the reference). */
 int m0_move_to_index_fen(int hip_device, const char* fen, const char* uci, int32_t* idx);
 
@@ -143,6 +146,7 @@ typedef struct m0_selfplay_cfg {
     uint64_t seed;                /* cfg["seed"] (1234) */
     int virtual_loss_active;      /* 1 = apply mcts.py:889-890/922-923 as written (the reference never does) */
     int ssl_in_forward;           /* run the SSL heads in every leaf evaluation (BASELINE config 4) */
+    int ssl_targets;              /* generate ssl_* target maps for every recorded ply (selfplay/internal.py:460-482) */
     int record_games;             /* keep s/pi/legal_mask per ply for m0_selfplay_poll */
 } m0_selfplay_cfg;
 
@@ -168,6 +172,7 @@ typedef struct m0_game_record {
     const uint8_t* legal_mask;    /* [T,4672] */
     const float* search_values;   /* [T] root_q per ply */
     const uint16_t* played;       /* [total_plies] moves incl. opening plies */
+    const float* ssl;             /* [T,17,8,8] piece(13) threat pin fork control, or NULL */
     void* owner;
 } m0_game_record;
 

@@ -333,17 +333,39 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
             abase[mi] = ok ? Ab + pp * 128 : Z_lds;
             afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
         }
-        static_for<0, 4>([&](auto kk_) __attribute__((always_inline)) {
+        // Fragment reads are software-pipelined by hand: the 7 ds_read_b128 of k-step kk+1 are issued under
+        // the 10 MFMAs of k-step kk (two register sets), instead of a wait in front of every MFMA pair.
+        half8 fa0[2], fa1[2], fb[2][NT];
+        auto load_frags = [&](auto kk_, auto buf_) __attribute__((always_inline)) {
             constexpr int kk = decltype(kk_)::value;
-            const half8 af0 = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
-            const half8 af1 = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
+            constexpr int bf = decltype(buf_)::value;
+            fa0[bf] = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
+            fa1[bf] = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
             const int woff = 16 * (wfx ^ (kk << 1));
             static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
                 constexpr int ni = decltype(ni_)::value;
-                const half8 bf = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
-                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf, acc[0][ni], 0, 0, 0);
-                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf, acc[1][ni], 0, 0, 0);
+                fb[bf][ni] = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
             });
+        };
+        load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, 4>([&](auto kk_) __attribute__((always_inline)) {
+            constexpr int kk = decltype(kk_)::value;
+            constexpr int cur = kk & 1;
+            if constexpr (kk < 3) load_frags(std::integral_constant<int, kk + 1>{}, std::integral_constant<int, cur ^ 1>{});
+            static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+                constexpr int ni = decltype(ni_)::value;
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[cur], fb[cur][ni], acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[cur], fb[cur][ni], acc[1][ni], 0, 0, 0);
+            });
+            if constexpr (kk < 3) {
+                // issue order inside this k-step: one LDS read after each of the first seven MFMAs
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            }
         });
     }
 

@@ -26,7 +26,7 @@ inline double now_ms() {
 }
 
 struct GameRecordOwner {
-    std::vector<float> s, pi, z, search_values;
+    std::vector<float> s, pi, z, search_values, ssl;
     std::vector<uint8_t> legal_mask;
     std::vector<uint16_t> played;
 };
@@ -37,6 +37,7 @@ struct HostGame {
     Pos pos;
     RepWindow win;
     std::vector<Move> history;            // all moves incl. opening plies
+    std::vector<Pos> rec_pos;             // position of every recorded ply (SSL targets)
     // records
     std::vector<float> states, pis, search_values;
     std::vector<int8_t> turns;
@@ -205,6 +206,20 @@ void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool ha
         o->z.resize(hgm.nstates);
         for (int i = 0; i < hgm.nstates; ++i) o->z[i] = z * (float)hgm.turns[i];
         o->played.assign(hgm.history.begin(), hgm.history.end());
+        if (c.ssl_targets && (int)hgm.rec_pos.size() == hgm.nstates) {
+            // targets for all plies of the game in one launch on the engine stream
+            const int T = hgm.nstates;
+            Pos* dp = nullptr; float* dout = nullptr;
+            if (hipMalloc((void**)&dp, sizeof(Pos) * T) == hipSuccess && hipMalloc((void**)&dout, (size_t)T * 17 * 64 * 4) == hipSuccess) {
+                o->ssl.resize((size_t)T * 17 * 64);
+                (void)hipMemcpyAsync(dp, hgm.rec_pos.data(), sizeof(Pos) * T, hipMemcpyHostToDevice, sp->stream);
+                (void)launch_ssl_targets(dp, T, dout, sp->stream);
+                (void)hipMemcpyAsync(o->ssl.data(), dout, (size_t)T * 17 * 64 * 4, hipMemcpyDeviceToHost, sp->stream);
+                (void)hipStreamSynchronize(sp->stream);
+            }
+            if (dp) (void)hipFree(dp);
+            if (dout) (void)hipFree(dout);
+        }
         m0_game_record r;
         memset(&r, 0, sizeof(r));
         r.game_index = hgm.game_index; r.moves = hgm.nstates; r.resigned = resigned ? 1 : 0; r.resigner = resigner;
@@ -215,6 +230,7 @@ void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool ha
         r.secs = (now_ms() - hgm.t0) / 1000.0;
         r.s = o->s.data(); r.pi = o->pi.data(); r.z = o->z.data(); r.legal_mask = o->legal_mask.data();
         r.search_values = o->search_values.data(); r.played = o->played.data(); r.owner = o;
+        r.ssl = o->ssl.empty() ? nullptr : o->ssl.data();
         sp->done_meta.push_back(r);
     }
     hgm.in_use = false;
@@ -245,6 +261,7 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
         for (int i = 0; i < k; ++i) pi[R.child_idx[i]] = (float)((double)R.child_n[i] / (double)total);
         hgm.states.resize((T + 1) * 19 * 64);
         encode_planes_f32(hgm.pos, hgm.states.data() + T * 19 * 64);
+        if (c.ssl_targets) hgm.rec_pos.push_back(hgm.pos);
         hgm.masks.resize((T + 1) * 4672, 0);
         uint8_t* mk = hgm.masks.data() + T * 4672;
         for (int i = 0; i < k; ++i) mk[R.child_idx[i]] = 1;
@@ -635,6 +652,28 @@ int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes
     }
     if (dp) (void)hipFree(dp); if (dpl) (void)hipFree(dpl); if (dm) (void)hipFree(dm);
     if (dn) (void)hipFree(dn); if (dmv) (void)hipFree(dmv); if (di) (void)hipFree(di);
+    return rc;
+}
+
+int m0_ssl_targets_fens(int hip_device, const char* const* fens, int n, float* out) {
+    if (!fens || n <= 0 || !out) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { m0_set_error("no HIP device available (no CPU fallback)"); return M0_ERR_HIP; }
+    if (hipSetDevice(hip_device) != hipSuccess) { m0_set_error("hipSetDevice failed"); return M0_ERR_HIP; }
+    std::vector<Pos> hp(n);
+    for (int i = 0; i < n; ++i)
+        if (!fens[i] || parse_fen(fens[i], hp[i]) != 0) { m0_set_error(std::string("bad FEN at index ") + std::to_string(i)); return M0_ERR_INVALID; }
+    Pos* dp = nullptr; float* dout = nullptr;
+    int rc = M0_OK;
+    if (hipMalloc((void**)&dp, sizeof(Pos) * n) != hipSuccess || hipMalloc((void**)&dout, (size_t)n * 17 * 64 * 4) != hipSuccess) {
+        m0_set_error("hipMalloc failed"); rc = M0_ERR_HIP;
+    } else {
+        (void)hipMemcpy(dp, hp.data(), sizeof(Pos) * n, hipMemcpyHostToDevice);
+        if (launch_ssl_targets(dp, n, dout, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { m0_set_error("ssl kernel failed"); rc = M0_ERR_HIP; }
+        else (void)hipMemcpy(out, dout, (size_t)n * 17 * 64 * 4, hipMemcpyDeviceToHost);
+    }
+    if (dp) (void)hipFree(dp);
+    if (dout) (void)hipFree(dout);
     return rc;
 }
 

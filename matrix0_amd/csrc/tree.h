@@ -113,3 +113,6 @@ hipError_t launch_encode_positions(const m0::Pos* pos_dev, int n, float* planes_
                                    _Float16* nhwc_dev /*[n][64][32] or null*/, uint8_t* mask_dev /*[n][4672]*/,
                                    int32_t* nlegal_dev, uint16_t* moves_dev /*[n][256]*/, int32_t* idx_dev /*[n][256]*/,
                                    hipStream_t st);
+
+// SSL training targets for recorded positions: out f32 [n][17][64] (piece 13, threat, pin, fork, control)
+hipError_t launch_ssl_targets(const m0::Pos* pos_dev, int n, float* out_dev, hipStream_t st);

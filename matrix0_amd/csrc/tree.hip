@@ -557,3 +557,73 @@ hipError_t launch_encode_positions(const Pos* pos_dev, int n, float* planes, _Fl
     hipLaunchKernelGGL(encode_positions_kernel, dim3(n), dim3(64), 0, st, pos_dev, n, planes, nhwc, mask, nlegal, moves, idxs);
     return hipGetLastError();
 }
+
+// ---- SSL training targets (azchess/ssl_algorithms.py:51-143, 256-557), one wave per position, lane = tensor square.
+// All geometry in tensor space (row 0 = rank 8) exactly as the reference computes it, quirks included (SURVEY B-5):
+// white pawns attack toward higher row index; the reference's pin map is identically zero (it ANDs a map that is
+// non-zero only on the candidate square with one non-zero only on the next square).
+// out f32 [n][17][64]: piece one-hot (13), threat, pin, fork, control.
+__global__ __launch_bounds__(64) void ssl_targets_kernel(const Pos* pos, int n, float* out) {
+    __shared__ int8_t pc[64];          // plane index 0..11 (white P..K, black P..K) or -1, by tensor square
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const Pos p = pos[i];
+    pc[lane] = (int8_t)piece_plane(p, (7 - (lane >> 3)) * 8 + (lane & 7));
+    __syncthreads();
+    const int r = lane >> 3, c = lane & 7;
+    const bool stm_white = p.turn == WHITE;
+    auto at = [&](int rr, int cc) -> int { return ((unsigned)rr < 8u && (unsigned)cc < 8u) ? (int)pc[rr * 8 + cc] : -2; };
+    const int KN[8][2] = {{-2, -1}, {-2, 1}, {-1, -2}, {-1, 2}, {1, -2}, {1, 2}, {2, -1}, {2, 1}};
+    const int KG[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
+    int wa = 0, ba = 0;
+    // pawns: white pawn at (r0,c0) attacks (r0+1,c0+-1); black pawn attacks (r0-1,c0+-1)
+    for (int dc = -1; dc <= 1; dc += 2) {
+        if (at(r - 1, c + dc) == 0) ++wa;
+        if (at(r + 1, c + dc) == 6) ++ba;
+    }
+    for (int k = 0; k < 8; ++k) {
+        int q = at(r + KN[k][0], c + KN[k][1]);
+        if (q == 1) ++wa; else if (q == 7) ++ba;
+        q = at(r + KG[k][0], c + KG[k][1]);
+        if (q == 5) ++wa; else if (q == 11) ++ba;
+    }
+    const int me = pc[lane];
+    const bool own_tactical = me >= 0 && ((stm_white && me >= 1 && me <= 5) || (!stm_white && me >= 7 && me <= 11));
+    const int mytype = me >= 0 ? me % 6 : -1;          // 0 P,1 N,2 B,3 R,4 Q,5 K
+    int forks = 0;
+    if (own_tactical && (mytype == 1 || mytype == 5)) {
+        for (int k = 0; k < 8; ++k) {
+            const int q = mytype == 1 ? at(r + KN[k][0], c + KN[k][1]) : at(r + KG[k][0], c + KG[k][1]);
+            if (q >= 0 && ((q < 6) != stm_white)) ++forks;
+        }
+    }
+    for (int k = 0; k < 8; ++k) {                       // the 8 ray directions (KG is also the ray set)
+        const int dr = KG[k][0], dc = KG[k][1];
+        const bool diag = dr != 0 && dc != 0;
+        int rr = r + dr, cc = c + dc, q = -1;
+        while ((unsigned)rr < 8u && (unsigned)cc < 8u) {
+            q = pc[rr * 8 + cc];
+            if (q >= 0) break;
+            rr += dr; cc += dc;
+        }
+        if (q < 0) continue;
+        const int t = q % 6;
+        // the first piece along the ray attacks this square if it slides along the ray
+        if (t == 4 || (diag && t == 2) || (!diag && t == 3)) { if (q < 6) ++wa; else ++ba; }
+        // and this square's own slider attacks that first piece if it is an enemy
+        if (own_tactical && (mytype == 4 || (diag && mytype == 2) || (!diag && mytype == 3)) && ((q < 6) != stm_white)) ++forks;
+    }
+    float* o = out + (size_t)i * 17 * 64;
+    for (int k = 0; k < 12; ++k) o[k * 64 + lane] = me == k ? 1.f : 0.f;
+    o[12 * 64 + lane] = me < 0 ? 1.f : 0.f;
+    o[13 * 64 + lane] = (stm_white ? ba : wa) > 0 ? 1.f : 0.f;
+    o[14 * 64 + lane] = 0.f;
+    o[15 * 64 + lane] = (own_tactical && forks >= 2) ? 1.f : 0.f;
+    o[16 * 64 + lane] = wa > ba ? 1.f : (wa < ba ? -1.f : 0.f);
+}
+
+hipError_t launch_ssl_targets(const Pos* pos_dev, int n, float* out_dev, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ssl_targets_kernel, dim3(n), dim3(64), 0, st, pos_dev, n, out_dev);
+    return hipGetLastError();
+}

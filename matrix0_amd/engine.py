@@ -27,7 +27,7 @@ class SelfplayCfg(C.Structure):
         ("draw_enabled", c_int), ("draw_min_plies", c_int), ("draw_window", c_int), ("draw_min_unique", c_int),
         ("draw_halfmove_cap", c_int), ("draw_material_threshold", c_int), ("draw_stalemate", c_int),
         ("concurrent_games", c_int), ("total_games", c_int), ("first_game_index", c_int), ("arena_nodes", c_int),
-        ("seed", c_u64), ("virtual_loss_active", c_int), ("ssl_in_forward", c_int), ("record_games", c_int),
+        ("seed", c_u64), ("virtual_loss_active", c_int), ("ssl_in_forward", c_int), ("ssl_targets", c_int), ("record_games", c_int),
     ]
 
 
@@ -42,7 +42,7 @@ class GameRecord(C.Structure):
                 ("total_plies", c_int), ("result", C.c_float), ("avg_policy_entropy", C.c_float), ("avg_sims", C.c_float),
                 ("secs", c_double), ("s", C.POINTER(C.c_float)), ("pi", C.POINTER(C.c_float)), ("z", C.POINTER(C.c_float)),
                 ("legal_mask", C.POINTER(C.c_uint8)), ("search_values", C.POINTER(C.c_float)),
-                ("played", C.POINTER(C.c_uint16)), ("owner", C.c_void_p)]
+                ("played", C.POINTER(C.c_uint16)), ("ssl", C.POINTER(C.c_float)), ("owner", C.c_void_p)]
 
 
 _bound = False
@@ -71,6 +71,7 @@ def _bind():
     L.m0_search_advance.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int]
     L.m0_encode_fens.argtypes = [c_int, C.POINTER(C.c_char_p), c_int] + [C.c_void_p] * 5
     L.m0_move_to_index_fen.argtypes = [c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
+    L.m0_ssl_targets_fens.argtypes = [c_int, C.POINTER(C.c_char_p), c_int, C.c_void_p]
     L.m0_sample_move_index.argtypes = [C.c_void_p, c_int, c_double, c_double]
     L.m0_playout_cap.argtypes = [c_int, c_double, c_double]
     L.m0_temperature_for.argtypes = [c_int, c_double, c_double, c_int]
@@ -84,7 +85,7 @@ def _bind():
 def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int = 0, first_game_index: int = 0,
                            seed: Optional[int] = None, leaves_per_step: Optional[int] = None,
                            virtual_loss_active: bool = True, ssl_in_forward: bool = False,
-                           record_games: bool = True, arena_nodes: int = 0) -> SelfplayCfg:
+                           record_games: bool = True, arena_nodes: int = 0, ssl_targets: bool = False) -> SelfplayCfg:
     """Merge config.yaml's `mcts`, `selfplay` and draw sections exactly as selfplay_worker does
     (azchess/selfplay/internal.py:192-199, 269-304) into the engine's C struct.  MCTSConfig
     defaults are the dataclass defaults of azchess/mcts.py:61-107."""
@@ -146,6 +147,7 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     c.seed = int(cfg.get("seed", 1234) if seed is None else seed)
     c.virtual_loss_active = int(bool(virtual_loss_active))
     c.ssl_in_forward = int(bool(ssl_in_forward))
+    c.ssl_targets = int(bool(ssl_targets))
     c.record_games = int(bool(record_games))
     return c
 
@@ -200,6 +202,11 @@ class SelfplayEngine:
                 "search_values": np.ctypeslib.as_array(r.search_values, shape=(T,)).copy(),
                 "played": [move_to_uci(int(x)) for x in np.ctypeslib.as_array(r.played, shape=(r.total_plies,))],
             }
+            if r.ssl:
+                ssl = np.ctypeslib.as_array(r.ssl, shape=(T, 17, 8, 8)).copy()
+                # NPZ field shapes of selfplay/internal.py:475-482: piece [T,13,8,8], the others [T,8,8]
+                out["ssl"] = {"piece": ssl[:, :13], "threat": ssl[:, 13], "pin": ssl[:, 14], "fork": ssl[:, 15],
+                              "control": ssl[:, 16]}
         finally:
             self._L.m0_game_record_free(C.byref(r))
         return out
@@ -275,3 +282,13 @@ def rules_probe(cfg: SelfplayCfg, fen: str, ucis: List[str]) -> dict:
     out = {name: bool(flags.value >> i & 1) for i, name in enumerate(RULE_FLAGS)}
     out["result"] = float(res.value)
     return out
+
+
+def ssl_targets_fens(fens, device_index: int = 0) -> dict:
+    """create_enhanced_ssl_targets (ssl_algorithms.py:519-543) on the device for a list of FENs."""
+    L = _bind()
+    n = len(fens)
+    arr = (C.c_char_p * n)(*[f.encode() for f in fens])
+    out = np.empty((n, 17, 8, 8), np.float32)
+    _lib.check(L.m0_ssl_targets_fens(int(device_index), arr, n, out.ctypes.data_as(C.c_void_p)), "m0_ssl_targets_fens")
+    return {"piece": out[:, :13], "threat": out[:, 13], "pin": out[:, 14], "fork": out[:, 15], "control": out[:, 16]}

@@ -58,11 +58,14 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     value_from_white = force_vfw or detect_value_from_white(backend)
     cfg2 = dict(cfg_dict)
     cfg2["mcts"] = dict(cfg_dict.get("mcts", {}) or {}, value_from_white=value_from_white)
+    # SSL targets are generated whenever the model has SSL enabled (selfplay/internal.py:312-318)
+    ssl_tasks = list(model_cfg.get("ssl_tasks", [])) if model_cfg.get("self_supervised", False) else []
     concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
     scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
                                   first_game_index=0, seed=base_seed + proc_id,
                                   leaves_per_step=eng_cfg.get("leaves_per_step", 16),
-                                  virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True)
+                                  virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
+                                  ssl_targets=bool(ssl_tasks))
     engine = SelfplayEngine(backend, scfg)
     writer = SelfplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"))
     last_hb = time.perf_counter()
@@ -85,6 +88,9 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                     "meta_avg_sims": np.array([rec["avg_sims"]], dtype=np.float32),
                     "legal_mask": rec["legal_mask"].astype(np.uint8),
                 }
+                for task in ssl_tasks:                              # internal.py:647-651
+                    if "ssl" in rec and task in rec["ssl"]:
+                        game_data[f"ssl_{task}"] = rec["ssl"][task].astype(np.float32)
                 filepath = writer.add_selfplay_data(game_data, worker_id=proc_id, game_id=rec["game_index"]) if T > 0 else None
                 done += 1
                 if q is not None:                                   # internal.py:665-679

@@ -56,3 +56,22 @@ def test_reference_unit_cases_on_device():
     assert np.array_equal(np.arange(73)[perm][perm], np.arange(73))
     rot = enc.build_rotate180_permutation()
     assert np.array_equal(np.arange(73)[rot][rot], np.arange(73))
+
+
+def test_ssl_targets_on_device_match_reference_goldens_and_oracle():
+    """ssl_algorithms.py targets computed by the HIP kernel: bit-exact vs the real reference's outputs
+    (tests/golden/ssl_targets.npz) and vs the oracle on further reference FENs."""
+    from matrix0_amd import engine as eng
+    from oracle import ssl_ref
+    z = np.load(os.path.join(GOLDEN, "ssl_targets.npz"))
+    fens = [str(f) for f in z["fens"]]
+    t = eng.ssl_targets_fens(fens)
+    for k in ("piece", "threat", "pin", "fork", "control"):
+        assert np.array_equal(t[k], z[k].astype(np.float32)), k
+    rows = json.load(gzip.open(os.path.join(GOLDEN, "tactical_legal_counts.json.gz"), "rt"))
+    fens2 = [r[0] for r in rows[7::40]]
+    t2 = eng.ssl_targets_fens(fens2)
+    for i, fen in enumerate(fens2):
+        o = ssl_ref.targets(ch.encode_board(ch.Board(fen)))
+        for k in ("piece", "threat", "pin", "fork", "control"):
+            assert np.array_equal(t2[k][i], o[k].astype(np.float32)), (fen, k)
