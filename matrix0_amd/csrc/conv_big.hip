@@ -1,0 +1,276 @@
+// conv_big_kernel: the dominant kernel of the network forward (3x3 / 1x1 implicit-GEMM conv on MFMA with
+// global_load_lds staging and fused block epilogues).  See net_kernels.hip's header for the design.
+#include "kernel_common.h"
+
+// ---------------------------------------------------------------------------
+// conv_big: the hot kernel (see file header)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 (hardware); the global source is per lane
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// EPI: 0 plain (bias/act/mul/scale + column sums), 1 fused GroupNorm16+act.  A template parameter so that each
+// epilogue gets its own register allocation.  (Fusing the SE gate + residual, or residual + LayerNorm, into this
+// epilogue was built and measured: correct but ~3x slower than conv + ew_board -- the per-board SE MLP is a
+// latency-bound GEMV that a 1-workgroup-per-CU kernel cannot hide -- so those passes stay in ew_board_kernel.)
+template <int TAPS, int EPI>
+__global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
+    constexpr int NT = 5;
+    constexpr int A_BYTES = 256 * 128;    // 4 boards x 64 squares x 64 channels fp16
+    constexpr int W_BYTES = 320 * 128;    // 320 output channels x 64 k fp16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* A_lds = smem;                   // [2][A_BYTES]
+    char* W_lds = smem + 2 * A_BYTES;     // [2][W_BYTES]
+    char* Z_lds = W_lds + 2 * W_BYTES;    // one all-zero square (128 B)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3;              // board within the tile
+    const int wn = wave >> 2;             // N half (160 channels = 10 GroupNorm groups)
+    const int m0 = blockIdx.x * 256;
+    const int n0 = blockIdx.y * 320;
+    const int Cin = a.Cin;
+    const int nchunk = Cin >> 6;
+    const int nsteps = nchunk * TAPS;
+    const int half = lane >> 5;
+
+    if (tid < 8) reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);
+
+    const char* in_bytes = reinterpret_cast<const char*>(a.in);
+    const char* w_bytes = reinterpret_cast<const char*>(a.w);
+
+    auto issue_A = [&](int chunk, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wave * 4 + i;                 // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
+            const int p = 8 * q + (lane >> 3);
+            const int cl = lane & 7;                    // LDS 16-byte chunk this lane fills
+            const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
+            glds16(src, A_lds + buf * A_BYTES + q * 1024);
+        }
+    };
+    auto issue_W = [&](int step, int buf) {
+        const int chunk = step / TAPS, tap = step - chunk * TAPS;
+        const char* src = w_bytes + ((size_t)(tap * nchunk + chunk) * a.Npad + n0) * 128;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = wave * 5 + i;
+            glds16(src + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
+        }
+    };
+    // single 1-KiB pieces, so the DMA issue (~100 cycles of the wave's issue slot each) can be spread between
+    // MFMA groups instead of stalling all eight waves right after the barrier
+    auto issue_W_piece = [&](const char* wsrc, int buf, int i) {
+        const int q = wave * 5 + i;
+        glds16(wsrc + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
+    };
+    auto issue_A_piece = [&](int chunk, int buf, int i) {
+        const int q = wave * 4 + i;
+        const int p = 8 * q + (lane >> 3);
+        const int cl = lane & 7;
+        const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
+        glds16(src, A_lds + buf * A_BYTES + q * 1024);
+    };
+
+    float16v acc[2][NT];
+    static_for<0, 2>([&](auto mi) __attribute__((always_inline)) {
+        static_for<0, NT>([&](auto ni) __attribute__((always_inline)) {
+            acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        });
+    });
+
+    // per-lane constants of the fragment reads
+    const int r31 = lane & 31;
+    const int wfx = ((r31 >> 1) & 7) ^ half;                           // weight rows: swizzle key ^ k-half
+    const int wrow_off = (wn * 160 + r31) * 128;
+    int prow[2], py[2], px[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        prow[mi] = wm * 64 + mi * 32 + r31;
+        py[mi] = (prow[mi] >> 3) & 7;
+        px[mi] = prow[mi] & 7;
+    }
+
+    // ---- main loop ----
+    // Stage s = (chunk, tap) weights in W buffer s&1, activations of chunk c in A buffer c&1.  Software pipeline:
+    //   * fragment reads run one k-step ahead of the MFMAs, ACROSS the step boundary (two register sets);
+    //   * one barrier per step, placed after the step's last LDS reads (before its 4th k-step): by then every wave
+    //     has waited for its DMA pieces of stage s+1 (issued one step earlier) and has finished reading stage s, so
+    //     after the barrier stage s+1 is visible and stage s's buffers are free;
+    //   * the DMA pieces of stage s+2 are issued right after that barrier, between the MFMA pairs of the 4th k-step.
+    half8 fa0[2], fa1[2], fb[2][NT];
+    const char* abase[2];
+    int afx[2];
+    const char* Wb;
+    auto set_addr = [&](int st_) __attribute__((always_inline)) {
+        const int ch = st_ / TAPS, tp = st_ - ch * TAPS;
+        const int dy = (TAPS == 9) ? (tp / 3 - 1) : 0;
+        const int dx = (TAPS == 9) ? (tp - (tp / 3) * 3 - 1) : 0;
+        const char* Ab = A_lds + (ch & 1) * A_BYTES;
+        Wb = W_lds + (st_ & 1) * W_BYTES + wrow_off;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int yy = py[mi] + dy, xx = px[mi] + dx;
+            const bool ok = (TAPS == 1) || ((unsigned)yy < 8u && (unsigned)xx < 8u);
+            const int pp = prow[mi] + dy * 8 + dx;
+            abase[mi] = ok ? Ab + pp * 128 : Z_lds;
+            afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
+        }
+    };
+    auto load_frags = [&](auto kk_, auto buf_) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_)::value;
+        constexpr int bf = decltype(buf_)::value;
+        fa0[bf] = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
+        fa1[bf] = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
+        const int woff = 16 * (wfx ^ (kk << 1));
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            fb[bf][ni] = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
+        });
+    };
+    auto mfma_set = [&](auto buf_) __attribute__((always_inline)) {
+        constexpr int cur = decltype(buf_)::value;
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[cur], fb[cur][ni], acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[cur], fb[cur][ni], acc[1][ni], 0, 0, 0);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    issue_A(0, 0);
+    issue_W(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nsteps > 1) {                       // stage 1 (its buffers have never been read)
+        issue_W(1, 1);
+        if (TAPS == 1) issue_A(1, 1);
+    }
+    set_addr(0);
+    load_frags(I0{}, I0{});
+    for (int s = 0; s < nsteps; ++s) {
+        load_frags(I1{}, I1{}); mfma_set(I0{});
+        load_frags(I2{}, I0{}); mfma_set(I1{});
+        load_frags(I3{}, I1{}); mfma_set(I0{});
+        // step boundary: stage s+1 landed + stage s no longer read
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int s2 = s + 2;
+        const bool more2 = s2 < nsteps;
+        const int ch2 = s2 / TAPS, tp2 = s2 - ch2 * TAPS;
+        const bool newA = more2 && tp2 == 0;
+        const char* wsrc = w_bytes + ((size_t)(tp2 * nchunk + ch2) * a.Npad + n0) * 128;
+        if (s + 1 < nsteps) set_addr(s + 1);
+        // 4th k-step: MFMAs of set 1, next step's first fragments into set 0, stage s+2 DMA pieces in between
+        if (s + 1 < nsteps) load_frags(I0{}, I0{});
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[1], fb[1][ni], acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[1], fb[1][ni], acc[1][ni], 0, 0, 0);
+            if (more2) issue_W_piece(wsrc, s2 & 1, ni);
+            if constexpr (ni < 4) { if (newA) issue_A_piece(ch2, ch2 & 1, ni); }
+        });
+    }
+
+    // ---------------- epilogue ----------------
+    const int ldo = a.ldo;
+    const int rowbase = m0 + wm * 64 + 4 * half;
+    const int colbase = n0 + wn * 160 + r31;
+    if constexpr (EPI == 1) {
+        // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
+        const int act = a.epi_act;
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            const int col = colbase + ni * 32;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                const float16v av = acc[decltype(mi_)::value][ni];
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+            });
+#pragma unroll
+            for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            const float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
+            const float sh = a.gn_beta[col] - mean * g;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                constexpr int mi = decltype(mi_)::value;
+                const float16v av = acc[mi][ni];
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = act_apply(av[r] * g + sh, act);
+                    if (row < a.Mvalid) reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
+                });
+            });
+        });
+        return;
+    }
+    if constexpr (EPI == 0) {
+    const int epi_act = a.epi_act;
+    const float oscale = a.out_scale;
+    const bool has_mul = a.mul != nullptr;
+    const bool f32out = a.out_f32 != 0;
+    const bool want_stats = a.out_stats != nullptr;
+    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+        constexpr int ni = decltype(ni_)::value;
+        const int col = colbase + ni * 32;
+        const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
+        float s = 0.f, ss = 0.f;
+        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+            constexpr int mi = decltype(mi_)::value;
+            const float16v av = acc[mi][ni];
+            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_)::value;
+                const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                float v = av[r] + bias;
+                if (epi_act != ACT_NONE) v = act_apply(v, epi_act);
+                if (has_mul) v *= (float)a.mul[(size_t)row * ldo + col];
+                v *= oscale;
+                s += v; ss += v * v;
+                if (row < a.Mvalid) {
+                    if (f32out) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
+                    else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
+                }
+            });
+        });
+        if (want_stats) {
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            if (lane < 32) {
+                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * a.N + col) * 2;
+                st[0] = s; st[1] = ss;
+            }
+        }
+    });
+    }
+}
+
+template <int TAPS, int EPI>
+static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 2 * 256 * 128 + 2 * 320 * 128 + 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(a.Mrows / 256, a.Npad / 320);
+    hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI>), grid, dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
+    const bool gn = a.gn_gamma != nullptr;
+    if (taps == 9) return gn ? launch_conv_big_e<9, 1>(a, st) : launch_conv_big_e<9, 0>(a, st);
+    if (taps == 1) return gn ? hipErrorInvalidValue : launch_conv_big_e<1, 0>(a, st);
+    return hipErrorInvalidValue;
+}

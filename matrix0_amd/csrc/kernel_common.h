@@ -1,0 +1,35 @@
+// Shared device helpers of the network kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "net_kernels.h"
+
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// Compile-time loop: the body sees its index as an integral_constant, so every accumulator index is a
+// constant in the AST (a runtime- or late-unrolled index keeps the MFMA accumulators in scratch memory).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        case ACT_LEAKY: return v > 0.f ? v : 0.05f * v;
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+

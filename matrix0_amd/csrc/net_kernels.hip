@@ -22,37 +22,7 @@
 //       positional encoding, LayerNorm over C, output statistics.
 //   attn_core_kernel  ChessAttention scores/softmax/PV for one (board, head).
 //   planes_to_nhwc_kernel  f32 [B,19,8,8] -> fp16 [B,64,32].
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-#include <stdint.h>
-#include "net_kernels.h"
-
-#include <type_traits>
-#include <utility>
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float16v __attribute__((ext_vector_type(16)));
-
-// Compile-time loop: the body sees its index as an integral_constant, so every accumulator index is a
-// constant in the AST (a runtime- or late-unrolled index keeps the MFMA accumulators in scratch memory).
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case ACT_RELU: return v > 0.f ? v : 0.f;
-        case ACT_SILU: return v / (1.f + __expf(-v));
-        case ACT_LEAKY: return v > 0.f ? v : 0.05f * v;
-        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        case ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
+#include "kernel_common.h"
 
 // ---------------------------------------------------------------------------
 // conv_gemm
@@ -233,231 +203,6 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------
-// conv_big: the hot kernel (see file header)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    // LDS destination = wave-uniform base + lane*16 (hardware); the global source is per lane
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int TAPS>
-__global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
-    constexpr int NT = 5;
-    constexpr int A_BYTES = 256 * 128;    // 4 boards x 64 squares x 64 channels fp16
-    constexpr int W_BYTES = 320 * 128;    // 320 output channels x 64 k fp16
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* A_lds = smem;                   // [2][A_BYTES]
-    char* W_lds = smem + 2 * A_BYTES;     // [2][W_BYTES]
-    char* Z_lds = W_lds + 2 * W_BYTES;    // one all-zero square (128 B)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3;              // board within the tile
-    const int wn = wave >> 2;             // N half (160 channels = 10 GroupNorm groups)
-    const int m0 = blockIdx.x * 256;
-    const int n0 = blockIdx.y * 320;
-    const int Cin = a.Cin;
-    const int nchunk = Cin >> 6;
-    const int nsteps = nchunk * TAPS;
-    const int half = lane >> 5;
-
-    if (tid < 8) reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);
-
-    const char* in_bytes = reinterpret_cast<const char*>(a.in);
-    const char* w_bytes = reinterpret_cast<const char*>(a.w);
-
-    auto issue_A = [&](int chunk, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = wave * 4 + i;                 // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
-            const int p = 8 * q + (lane >> 3);
-            const int cl = lane & 7;                    // LDS 16-byte chunk this lane fills
-            const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
-            glds16(src, A_lds + buf * A_BYTES + q * 1024);
-        }
-    };
-    auto issue_W = [&](int step, int buf) {
-        const int chunk = step / TAPS, tap = step - chunk * TAPS;
-        const char* src = w_bytes + ((size_t)(tap * nchunk + chunk) * a.Npad + n0) * 128;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int q = wave * 5 + i;
-            glds16(src + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
-        }
-    };
-
-    float16v acc[2][NT];
-    static_for<0, 2>([&](auto mi) __attribute__((always_inline)) {
-        static_for<0, NT>([&](auto ni) __attribute__((always_inline)) {
-            acc[decltype(mi)::value][decltype(ni)::value] = float16v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                                                                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        });
-    });
-
-    // per-lane constants of the fragment reads
-    const int r31 = lane & 31;
-    const int wfx = ((r31 >> 1) & 7) ^ half;                           // weight rows: swizzle key ^ k-half
-    const int wrow_off = (wn * 160 + r31) * 128;
-    int prow[2], py[2], px[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        prow[mi] = wm * 64 + mi * 32 + r31;
-        py[mi] = (prow[mi] >> 3) & 7;
-        px[mi] = prow[mi] & 7;
-    }
-
-    issue_A(0, 0);
-    issue_W(0, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        const int chunk = s / TAPS, tap = s - chunk * TAPS;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage s have landed
-        __syncthreads();                                   // ... everyone's have; step s-1 reads are done
-        if (s + 1 < nsteps) {
-            issue_W(s + 1, (s + 1) & 1);
-            if (tap == TAPS - 1) issue_A(chunk + 1, (chunk + 1) & 1);
-        }
-        const int dy = (TAPS == 9) ? (tap / 3 - 1) : 0;
-        const int dx = (TAPS == 9) ? (tap - (tap / 3) * 3 - 1) : 0;
-        const char* Ab = A_lds + (chunk & 1) * A_BYTES;
-        const char* Wb = W_lds + (s & 1) * W_BYTES + wrow_off;
-        const char* abase[2];
-        int afx[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int yy = py[mi] + dy, xx = px[mi] + dx;
-            const bool ok = (TAPS == 1) || ((unsigned)yy < 8u && (unsigned)xx < 8u);
-            const int pp = prow[mi] + dy * 8 + dx;
-            abase[mi] = ok ? Ab + pp * 128 : Z_lds;
-            afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
-        }
-        // Fragment reads are software-pipelined by hand: the 7 ds_read_b128 of k-step kk+1 are issued under
-        // the 10 MFMAs of k-step kk (two register sets), instead of a wait in front of every MFMA pair.
-        half8 fa0[2], fa1[2], fb[2][NT];
-        auto load_frags = [&](auto kk_, auto buf_) __attribute__((always_inline)) {
-            constexpr int kk = decltype(kk_)::value;
-            constexpr int bf = decltype(buf_)::value;
-            fa0[bf] = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (kk << 1)));
-            fa1[bf] = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (kk << 1)));
-            const int woff = 16 * (wfx ^ (kk << 1));
-            static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-                constexpr int ni = decltype(ni_)::value;
-                fb[bf][ni] = *reinterpret_cast<const half8*>(Wb + ni * 4096 + woff);
-            });
-        };
-        load_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        static_for<0, 4>([&](auto kk_) __attribute__((always_inline)) {
-            constexpr int kk = decltype(kk_)::value;
-            constexpr int cur = kk & 1;
-            if constexpr (kk < 3) load_frags(std::integral_constant<int, kk + 1>{}, std::integral_constant<int, cur ^ 1>{});
-            static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-                constexpr int ni = decltype(ni_)::value;
-                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[cur], fb[cur][ni], acc[0][ni], 0, 0, 0);
-                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[cur], fb[cur][ni], acc[1][ni], 0, 0, 0);
-            });
-            if constexpr (kk < 3) {
-                // issue order inside this k-step: one LDS read after each of the first seven MFMAs
-#pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            }
-        });
-    }
-
-    // ---------------- epilogue ----------------
-    const int ldo = a.ldo;
-    const int rowbase = m0 + wm * 64 + 4 * half;
-    const int colbase = n0 + wn * 160 + r31;
-    if (a.gn_gamma != nullptr) {
-        // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
-        const int act = a.epi_act;
-        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-            constexpr int ni = decltype(ni_)::value;
-            const int col = colbase + ni * 32;
-            float s = 0.f, ss = 0.f;
-            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-                const float16v av = acc[decltype(mi_)::value][ni];
-                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
-            });
-#pragma unroll
-            for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-            const float mean = s * (1.f / 1024.f);
-            float var = ss * (1.f / 1024.f) - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
-            const float sh = a.gn_beta[col] - mean * g;
-            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-                constexpr int mi = decltype(mi_)::value;
-                const float16v av = acc[mi][ni];
-                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
-                    constexpr int r = decltype(r_)::value;
-                    const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = act_apply(av[r] * g + sh, act);
-                    if (row < a.Mvalid) reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
-                });
-            });
-        });
-        return;
-    }
-    const int epi_act = a.epi_act;
-    const float oscale = a.out_scale;
-    const bool has_mul = a.mul != nullptr;
-    const bool f32out = a.out_f32 != 0;
-    const bool want_stats = a.out_stats != nullptr;
-    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-        constexpr int ni = decltype(ni_)::value;
-        const int col = colbase + ni * 32;
-        const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
-        float s = 0.f, ss = 0.f;
-        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-            constexpr int mi = decltype(mi_)::value;
-            const float16v av = acc[mi][ni];
-            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
-                constexpr int r = decltype(r_)::value;
-                const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                float v = av[r] + bias;
-                if (epi_act != ACT_NONE) v = act_apply(v, epi_act);
-                if (has_mul) v *= (float)a.mul[(size_t)row * ldo + col];
-                v *= oscale;
-                s += v; ss += v * v;
-                if (row < a.Mvalid) {
-                    if (f32out) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
-                    else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
-                }
-            });
-        });
-        if (want_stats) {
-            s += __shfl_xor(s, 32);
-            ss += __shfl_xor(ss, 32);
-            if (lane < 32) {
-                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * a.N + col) * 2;
-                st[0] = s; st[1] = ss;
-            }
-        }
-    });
-}
-
-template <int TAPS>
-static hipError_t launch_conv_big_t(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = 2 * 256 * 128 + 2 * 320 * 128 + 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    dim3 grid(a.Mrows / 256, a.Npad / 320);
-    hipLaunchKernelGGL((conv_big_kernel<TAPS>), grid, dim3(512), lds, st, a);
-    return hipGetLastError();
-}
-
 template <int TAPS, int WN, int NT, int KC>
 static size_t conv_gemm_lds(int Cin) {
     constexpr int NB = WN * NT * 32;
@@ -483,6 +228,8 @@ static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
+
 int conv_gemm_tile_n(int Cin, int Npad) {
     return (Npad % 320 == 0 && Cin % 64 == 0) ? 320 : 32;
 }
@@ -495,10 +242,10 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     const bool big = conv_gemm_tile_n(a.Cin, a.Npad) == 320;
     if (a.gn_gamma != nullptr && !big) return hipErrorInvalidValue;   // fused GN epilogue: big tile only
     if (taps == 9) {
-        if (big) return launch_conv_big_t<9>(a, st);
+        if (big) return launch_conv_big(a, 9, st);
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
     } else if (taps == 1) {
-        if (big) return launch_conv_big_t<1>(a, st);
+        if (big) return launch_conv_big(a, 1, st);
         return launch_conv_gemm_t<1, 1, 1, 32>(a, st);
     }
     return hipErrorInvalidValue;
