@@ -183,18 +183,20 @@ M0_HD bool legal_after(const Pos& p, Move m) {
     return k < 0 || !attacked(q, k, p.turn ^ 1);
 }
 
+template <bool LEGAL>
 M0_HD int emit(const Pos& p, Move* out, int n, int from, int to, int promo) {
     Move m = mk_move(from, to, promo);
-    if (legal_after(p, m)) out[n++] = m;
+    if (!LEGAL || legal_after(p, m)) out[n++] = m;
     return n;
 }
+template <bool LEGAL>
 M0_HD int emit_promos(const Pos& p, Move* out, int n, int from, int to) {
     if ((to >> 3) == 0 || (to >> 3) == 7) {
-        n = emit(p, out, n, from, to, 4); n = emit(p, out, n, from, to, 3);
-        n = emit(p, out, n, from, to, 2); n = emit(p, out, n, from, to, 1);
+        n = emit<LEGAL>(p, out, n, from, to, 4); n = emit<LEGAL>(p, out, n, from, to, 3);
+        n = emit<LEGAL>(p, out, n, from, to, 2); n = emit<LEGAL>(p, out, n, from, to, 1);
         return n;
     }
-    return emit(p, out, n, from, to, 0);
+    return emit<LEGAL>(p, out, n, from, to, 0);
 }
 M0_HD uint64_t piece_targets(const Pos& p, int from, int type) {
     const uint64_t o = occ_all(p);
@@ -208,23 +210,27 @@ M0_HD uint64_t piece_targets(const Pos& p, int from, int type) {
     }
     return a & ~p.occ[p.turn];
 }
+template <bool LEGAL>
 M0_HD int emit_piece(const Pos& p, Move* out, int n, int from) {
     uint64_t t = piece_targets(p, from, piece_type_at(p, from));
-    while (t) { int to = msb(t); t &= ~bit(to); n = emit(p, out, n, from, to, 0); }
+    while (t) { int to = msb(t); t &= ~bit(to); n = emit<LEGAL>(p, out, n, from, to, 0); }
     return n;
 }
 
-// Legal moves in python-chess generation order (see oracle/chess_oracle.c header).
-M0_HD int gen_legal(const Pos& p, Move* out) {
+// Moves in python-chess generation order (see oracle/chess_oracle.c header).  LEGAL = true: the legal moves.
+// LEGAL = false: the pseudo-legal superset in the same order (castling entries already fully checked); filtering it
+// with legal_after() move by move -- which the device does one move per lane -- gives exactly the LEGAL = true list.
+template <bool LEGAL>
+M0_HD int gen_moves(const Pos& p, Move* out) {
     int n = 0;
     const int us = p.turn, them = us ^ 1;
     const uint64_t own = p.occ[us], o = occ_all(p);
     const int ksq = king_sq(p, us);
     const bool chk = ksq >= 0 && attacked(p, ksq, them);
-    if (chk) n = emit_piece(p, out, n, ksq);
+    if (chk) n = emit_piece<LEGAL>(p, out, n, ksq);
     uint64_t pcs = own & ~p.bb[PAWN];
     if (chk && ksq >= 0) pcs &= ~bit(ksq);
-    while (pcs) { int s = msb(pcs); pcs &= ~bit(s); n = emit_piece(p, out, n, s); }
+    while (pcs) { int s = msb(pcs); pcs &= ~bit(s); n = emit_piece<LEGAL>(p, out, n, s); }
     if (!chk && ksq >= 0) {
         const int cr = clean_cr(p);
         const int base = us == WHITE ? 0 : 56;
@@ -243,24 +249,26 @@ M0_HD int gen_legal(const Pos& p, Move* out) {
     while (c) {
         int s = msb(c); c &= ~bit(s);
         uint64_t t = pawn_att(s, us) & p.occ[them];
-        while (t) { int to = msb(t); t &= ~bit(to); n = emit_promos(p, out, n, s, to); }
+        while (t) { int to = msb(t); t &= ~bit(to); n = emit_promos<LEGAL>(p, out, n, s, to); }
     }
     uint64_t single = (us == WHITE ? pawns << 8 : pawns >> 8) & ~o;
     uint64_t dbl = (us == WHITE ? single << 8 : single >> 8) & ~o & (us == WHITE ? (RANK_1 << 24) : (RANK_1 << 32));
     while (single) {
         int to = msb(single); single &= ~bit(to);
-        n = emit_promos(p, out, n, to + (us == WHITE ? -8 : 8), to);
+        n = emit_promos<LEGAL>(p, out, n, to + (us == WHITE ? -8 : 8), to);
     }
     while (dbl) {
         int to = msb(dbl); dbl &= ~bit(to);
-        n = emit(p, out, n, to + (us == WHITE ? -16 : 16), to, 0);
+        n = emit<LEGAL>(p, out, n, to + (us == WHITE ? -16 : 16), to, 0);
     }
     if (p.ep >= 0 && !(o & bit(p.ep))) {
         uint64_t cap = pawns & pawn_att(p.ep, them) & (us == WHITE ? (RANK_1 << 32) : (RANK_1 << 24));
-        while (cap) { int s = msb(cap); cap &= ~bit(s); n = emit(p, out, n, s, p.ep, 0); }
+        while (cap) { int s = msb(cap); cap &= ~bit(s); n = emit<LEGAL>(p, out, n, s, p.ep, 0); }
     }
     return n;
 }
+M0_HD int gen_legal(const Pos& p, Move* out) { return gen_moves<true>(p, out); }
+M0_HD int gen_pseudo(const Pos& p, Move* out) { return gen_moves<false>(p, out); }
 
 M0_HD bool has_legal_ep(const Pos& p) {
     if (p.ep < 0 || (occ_all(p) & bit(p.ep))) return false;

@@ -420,6 +420,7 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     sp->d.games = dalloc<GameDev>(sp, sp->G);
     sp->d.samples = dalloc<Sample>(sp, (size_t)sp->G * sp->L);
     sp->d.paths = dalloc<int>(sp, (size_t)sp->G * sp->L * M0_MAX_DEPTH);
+    sp->d.leaf_moves = dalloc<uint16_t>(sp, (size_t)sp->G * sp->L * M0_MAX_CHILDREN);
     sp->d.hist = dalloc<uint64_t>(sp, (size_t)sp->G * M0_HIST_CAP);
     sp->d.results = dalloc<RootResult>(sp, sp->G);
     sp->d.row_counter = dalloc<int>(sp, 4);
@@ -433,7 +434,7 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     sp->d.logits = sp->logits_dev; sp->d.values = sp->values_dev;
     sp->d.G = sp->G; sp->d.L = sp->L;
     bool ok = t.prior && t.w && t.q && t.n && t.vl && t.cbase && t.nch && t.mv && t.midx && sp->d.games && sp->d.samples &&
-              sp->d.paths && sp->d.hist && sp->d.results && sp->d.row_counter && sp->d.x0 && sp->logits_dev && sp->values_dev &&
+              sp->d.paths && sp->d.leaf_moves && sp->d.hist && sp->d.results && sp->d.row_counter && sp->d.x0 && sp->logits_dev && sp->values_dev &&
               sp->ids_dev && sp->slots_dev;
     if (!ok) {
         m0_set_error("hipMalloc failed for the search arenas (lower concurrent_games or arena_nodes)");

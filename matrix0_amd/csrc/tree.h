@@ -59,6 +59,7 @@ struct Sample {
     int leaf;
     int depth;                // path has depth+1 nodes
     int row;                  // network batch row
+    int nlegal;               // legal moves of the leaf (list in TreeDev::leaf_moves), filled by select
 };
 
 struct TreeArrays {           // each [G][2*cap]
@@ -91,6 +92,7 @@ struct TreeDev {
     GameDev* games;           // [G]
     Sample* samples;          // [G][L]
     int* paths;               // [G][L][M0_MAX_DEPTH]
+    uint16_t* leaf_moves;     // [G][L][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order
     uint64_t* hist;           // [G][M0_HIST_CAP]
     RootResult* results;      // [G]
     int* row_counter;         // [1]

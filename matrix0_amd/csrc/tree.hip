@@ -67,6 +67,25 @@ __device__ __forceinline__ Arena arena_of(const TreeArrays& t, int g, int half) 
     return a;
 }
 
+// Legal moves in generation order, the legality test (make + king-attack) spread one move per lane:
+// pseudo-legal list (sequential, uniform across lanes, cheap bitboard work) -> per-lane legal_after() ->
+// order-preserving ballot compaction.  Same list as gen_legal() (tests/test_chess_core_host.py).
+__device__ int gen_legal_wave(const Pos& p, Move* out_lds, Move* tmp_lds, int lane) {
+    const int np = gen_pseudo(p, tmp_lds);
+    __syncthreads();
+    int base = 0;
+    for (int k0 = 0; k0 < np; k0 += 64) {
+        const int i = k0 + lane;
+        const Move m = i < np ? tmp_lds[i] : (Move)0;
+        const bool ok = i < np && legal_after(p, m);
+        const unsigned long long mask = __ballot(ok);
+        if (ok) out_lds[base + __popcll(mask & ((1ull << lane) - 1ull))] = m;
+        base += __popcll(mask);
+    }
+    __syncthreads();
+    return base;
+}
+
 // lane = tensor square n (row-major, row 0 = rank 8): 32 fp16 channels (19 used)
 __device__ void encode_nhwc(const Pos& p, _Float16* dst /*[64][32]*/, int lane) {
     const int s = (7 - (lane >> 3)) * 8 + (lane & 7);
@@ -120,10 +139,12 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     __shared__ uint64_t pkey[M0_MAX_DEPTH];
     __shared__ uint8_t pirr[M0_MAX_DEPTH];
     __shared__ Move smoves[M0_MAX_MOVES];
+    __shared__ Move spseudo[M0_MAX_MOVES];
     __shared__ double sg[M0_MAX_CHILDREN];
     const int g = blockIdx.x, lane = threadIdx.x;
     GameDev* gd = &d.games[g];
     if (!gd->active) { if (lane == 0) gd->nsamples = 0; return; }
+    uint16_t* LM = d.leaf_moves + (size_t)g * d.L * M0_MAX_CHILDREN;
     const Arena A = arena_of(d.t, g, gd->arena);
     const int root = gd->root;
     Sample* S = d.samples + (size_t)g * d.L;
@@ -140,8 +161,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         if (lane == 0) row = atomicAdd(d.row_counter, 1);
         row = __shfl(row, 0);
         const Pos rp = gd->root_pos;
+        const int nl = gen_legal_wave(rp, smoves, spseudo, lane);
+        for (int i = lane; i < nl; i += 64) LM[i] = smoves[i];
         if (lane == 0) {
-            Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row;
+            Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = nl;
             S[0] = s; P[0] = root; gd->nsamples = 1;
         }
         encode_nhwc(rp, d.x0 + (size_t)row * 64 * 32, lane);
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             __syncthreads();
         }
         // leaf: is_game_over() (checkmate, insufficient, stalemate, 75-move, fivefold) -> _terminal_value
-        const int nlegal = gen_legal(pos, smoves);
+        const int nlegal = gen_legal_wave(pos, smoves, spseudo, lane);
         const bool chk = in_check(pos);
         bool term = false;
         double tv = 0.0;
@@ -236,8 +259,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             row = __shfl(row, 0);
             encode_nhwc(pos, d.x0 + (size_t)row * 64 * 32, lane);
         }
+        if (!term) for (int i = lane; i < nlegal; i += 64) LM[(size_t)s * M0_MAX_CHILDREN + i] = smoves[i];
         if (lane == 0) {
             Sample smp; smp.pos = pos; smp.kind = term ? 3 : 1; smp.leaf = node; smp.depth = depth; smp.row = row;
+            smp.nlegal = nlegal;
             S[s] = smp;
             if (term) backprop(A, path, depth, tv);     // mcts.py:747-751: terminal leaves back up immediately
         }
@@ -261,9 +286,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // Node._expand (mcts.py:135-225) for one leaf; returns false if the arena is exhausted
 __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg& c, int leaf, const Pos& pos,
-                            const float* lg, Move* smoves, int lane) {
-    const int n = gen_legal(pos, smoves);
-    __syncthreads();
+                            const float* lg, const uint16_t* smoves, int n, int lane) {
+    // legal moves of the leaf come from select (same position, same order): no second move generation
     if (n <= 0) return true;
     // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
     bool bad = false;
@@ -383,10 +407,10 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
 }
 
 __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
-    __shared__ Move smoves[M0_MAX_MOVES];
     const int g = blockIdx.x, lane = threadIdx.x;
     GameDev* gd = &d.games[g];
     if (!gd->active) return;
+    const uint16_t* LM = d.leaf_moves + (size_t)g * d.L * M0_MAX_CHILDREN;
     const int ns = gd->nsamples;
     if (ns <= 0) return;
     const Arena A = arena_of(d.t, g, gd->arena);
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
             const float v = d.values[row];
             if (A.nch[leaf] < 0) {
                 const Pos pos = S[s].pos;
-                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, smoves, lane);
+                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane);
             }
             ++evals;
             if (kind == 1) {

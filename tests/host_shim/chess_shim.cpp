@@ -29,6 +29,15 @@ int hc_legal(const char* fen, int32_t* out_mv, int32_t* out_idx) {
     }
     return n;
 }
+// the device's two-phase generator (pseudo-legal list in order, then per-move legality filter) run sequentially
+int hc_legal_two_phase(const char* fen, int32_t* out_mv) {
+    Pos p; if (parse_fen(fen, p)) return -1;
+    Move pm[M0_MAX_MOVES];
+    int np = gen_pseudo(p, pm), n = 0;
+    for (int i = 0; i < np; ++i)
+        if (legal_after(p, pm[i])) { int pr = mv_promo(pm[i]); out_mv[n++] = mv_from(pm[i]) | (mv_to(pm[i]) << 8) | ((pr ? pr + 1 : 0) << 16); }
+    return n;
+}
 int hc_encode(const char* fen, float* out) { Pos p; if (parse_fen(fen, p)) return -1; encode_planes_f32(p, out); return 0; }
 
 // play uci moves from fen; report state: out[0]=in_check out[1]=insufficient out[2]=clean_cr out[3]=has_legal_ep

@@ -61,6 +61,16 @@ def test_move_order_indices_planes_on_reference_fens(shim):
         assert np.array_equal(buf, ch.encode_board(b)), fen
 
 
+def test_two_phase_generator_equals_sequential(shim):
+    """pseudo-legal list + per-move legality filter (what the tree kernels do one move per lane) == gen_legal."""
+    rows = json.load(gzip.open(os.path.join(HERE, "golden", "tactical_legal_counts.json.gz"), "rt"))
+    mv = (C.c_int32 * 256)()
+    for fen, n, _ in rows[::3]:
+        k = shim.hc_legal_two_phase(fen.encode(), mv)
+        assert k == n
+        assert [(mv[i] & 255, (mv[i] >> 8) & 255, (mv[i] >> 16) or None) for i in range(k)] == _legal(shim, fen)[0], fen
+
+
 def test_random_playouts_state_keys_irreversible(shim):
     rng = np.random.default_rng(11)
     for g in range(40):
