@@ -134,7 +134,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # M0_FORCE_DIST=1: take the RCCL path (init, weight broadcast, reductions) even with one rank -- lets the
+    # one-GPU box exercise exactly the code the multi-GPU runs use
+    distributed = world > 1 or (os.environ.get("M0_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

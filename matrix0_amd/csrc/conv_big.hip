@@ -15,9 +15,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // epilogue gets its own register allocation.  (Fusing the SE gate + residual, or residual + LayerNorm, into this
 // epilogue was built and measured: correct but ~3x slower than conv + ew_board -- the per-board SE MLP is a
 // latency-bound GEMV that a 1-workgroup-per-CU kernel cannot hide -- so those passes stay in ew_board_kernel.)
-template <int TAPS, int EPI>
-__global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
-    constexpr int NT = 5;
+// WNW: waves along N.  2: 8 waves (2 per SIMD), wave tile 64x160, <=256 VGPRs.  1: 4 waves (one per SIMD, the whole
+// 512-entry register file each), wave tile 64x320: 12 LDS fragment reads per 20 MFMAs instead of 7 per 10.
+template <int TAPS, int EPI, int WNW>
+__global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
+    constexpr int NT = 10 / WNW;
+    constexpr int NWAVES = 4 * WNW;
+    constexpr int WP = 40 / NWAVES;      // weight DMA pieces per wave and stage
+    constexpr int AP = 32 / NWAVES;      // activation DMA pieces per wave and chunk
     constexpr int A_BYTES = 256 * 128;    // 4 boards x 64 squares x 64 channels fp16
     constexpr int W_BYTES = 320 * 128;    // 320 output channels x 64 k fp16
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3;              // board within the tile
-    const int wn = wave >> 2;             // N half (160 channels = 10 GroupNorm groups)
+    const int wn = wave >> 2;             // N part (32*NT channels = 2*NT whole GroupNorm groups)
     const int m0 = blockIdx.x * 256;
     const int n0 = blockIdx.y * 320;
     const int Cin = a.Cin;
@@ -38,14 +43,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     const int half = lane >> 5;
 
     if (tid < 8) reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);
+    static_assert(WP >= 1 && AP >= 1 && NT >= WP, "piece distribution");
 
     const char* in_bytes = reinterpret_cast<const char*>(a.in);
     const char* w_bytes = reinterpret_cast<const char*>(a.w);
 
     auto issue_A = [&](int chunk, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = wave * 4 + i;                 // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
+        for (int i = 0; i < AP; ++i) {
+            const int q = wave * AP + i;                // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
             const int p = 8 * q + (lane >> 3);
             const int cl = lane & 7;                    // LDS 16-byte chunk this lane fills
             const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
@@ -56,19 +62,19 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
         const int chunk = step / TAPS, tap = step - chunk * TAPS;
         const char* src = w_bytes + ((size_t)(tap * nchunk + chunk) * a.Npad + n0) * 128;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int q = wave * 5 + i;
+        for (int i = 0; i < WP; ++i) {
+            const int q = wave * WP + i;
             glds16(src + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
         }
     };
     // single 1-KiB pieces, so the DMA issue (~100 cycles of the wave's issue slot each) can be spread between
     // MFMA groups instead of stalling all eight waves right after the barrier
     auto issue_W_piece = [&](const char* wsrc, int buf, int i) {
-        const int q = wave * 5 + i;
+        const int q = wave * WP + i;
         glds16(wsrc + q * 1024 + lane * 16, W_lds + buf * W_BYTES + q * 1024);
     };
     auto issue_A_piece = [&](int chunk, int buf, int i) {
-        const int q = wave * 4 + i;
+        const int q = wave * AP + i;
         const int p = 8 * q + (lane >> 3);
         const int cl = lane & 7;
         const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     // per-lane constants of the fragment reads
     const int r31 = lane & 31;
     const int wfx = ((r31 >> 1) & 7) ^ half;                           // weight rows: swizzle key ^ k-half
-    const int wrow_off = (wn * 160 + r31) * 128;
+    const int wrow_off = (wn * NT * 32 + r31) * 128;
     int prow[2], py[2], px[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -172,15 +178,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
             constexpr int ni = decltype(ni_)::value;
             acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0[1], fb[1][ni], acc[0][ni], 0, 0, 0);
             acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[1], fb[1][ni], acc[1][ni], 0, 0, 0);
-            if (more2) issue_W_piece(wsrc, s2 & 1, ni);
-            if constexpr (ni < 4) { if (newA) issue_A_piece(ch2, ch2 & 1, ni); }
+            if constexpr (ni < WP) { if (more2) issue_W_piece(wsrc, s2 & 1, ni); }
+            if constexpr (ni < AP) { if (newA) issue_A_piece(ch2, ch2 & 1, ni); }
         });
     }
 
     // ---------------- epilogue ----------------
     const int ldo = a.ldo;
     const int rowbase = m0 + wm * 64 + 4 * half;
-    const int colbase = n0 + wn * 160 + r31;
+    const int colbase = n0 + wn * NT * 32 + r31;
     if constexpr (EPI == 1) {
         // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
         const int act = a.epi_act;
@@ -253,24 +259,26 @@ __global__ __launch_bounds__(512) void conv_big_kernel(GemmArgs a) {
     }
 }
 
-template <int TAPS, int EPI>
+template <int TAPS, int EPI, int WNW>
 static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 2 * 256 * 128 + 2 * 320 * 128 + 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(a.Mrows / 256, a.Npad / 320);
-    hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW>), grid, dim3(256 * WNW), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
+    // WNW = 2 (8 waves).  The 4-wave / 512-register form (WNW = 1) was built and measured: numerically identical,
+    // 2x slower with hipcc's schedule (LDS latency exposed with one wave per SIMD, spills) -- not instantiated.
     const bool gn = a.gn_gamma != nullptr;
-    if (taps == 9) return gn ? launch_conv_big_e<9, 1>(a, st) : launch_conv_big_e<9, 0>(a, st);
-    if (taps == 1) return gn ? hipErrorInvalidValue : launch_conv_big_e<1, 0>(a, st);
+    if (taps == 9) return gn ? launch_conv_big_e<9, 1, 2>(a, st) : launch_conv_big_e<9, 0, 2>(a, st);
+    if (taps == 1) return gn ? hipErrorInvalidValue : launch_conv_big_e<1, 0, 2>(a, st);
     return hipErrorInvalidValue;
 }

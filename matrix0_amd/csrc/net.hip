@@ -3,6 +3,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <stdlib.h>
 
 #define HIPCHK(x)                                                                         \
     do {                                                                                  \
