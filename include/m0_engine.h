@@ -110,6 +110,9 @@ int m0_net_profile_get(m0_net* net, double* conv_ms, double* conv_flop, int64_t*
  *   moves u16 [n,256] (from | to<<6 | promo<<12, promo 1..4 = N,B,R,Q) in legal_moves order; idx i32 [n,256]. */
 int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes, uint8_t* mask, int32_t* nlegal,
                    uint16_t* moves, int32_t* idx);
+/* MoveEncoder.decode_move (encoding.py:174-229): policy index -> UCI (auto-queen, legal fallbacks); "0000" = null move.
+ * uci_out: at least 6 bytes. */
+int m0_decode_move_fen(int hip_device, const char* fen, int action_idx, char* uci_out);
 /* ChessSSLAlgorithms.create_enhanced_ssl_targets (azchess/ssl_algorithms.py:519-543) on the device:
  * out f32 [n,17,8,8] = piece one-hot (13) | threat | pin | fork | control, tensor orientation. */
 int m0_ssl_targets_fens(int hip_device, const char* const* fens, int n, float* out);

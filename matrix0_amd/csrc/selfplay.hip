@@ -694,6 +694,51 @@ int m0_move_to_index_fen(int hip_device, const char* fen, const char* uci, int32
     return M0_ERR_INVALID;
 }
 
+int m0_decode_move_fen(int hip_device, const char* fen, int action_idx, char* uci_out) {
+    if (!fen || !uci_out) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    if (action_idx < 0 || action_idx >= M0_POLICY_SIZE) { m0_set_error("action_idx out of range"); return M0_ERR_INVALID; }
+    Pos p;
+    if (parse_fen(fen, p) != 0) { m0_set_error("bad FEN"); return M0_ERR_INVALID; }
+    std::vector<uint16_t> mv(M0_MAX_MOVES);
+    int32_t n = 0;
+    const char* fens[1] = {fen};
+    int rc = m0_encode_fens(hip_device, fens, 1, nullptr, nullptr, &n, mv.data(), nullptr);   // legal moves from the device
+    if (rc != M0_OK) return rc;
+    static const int RAY[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+    static const int KN[8][2] = {{-2, -1}, {-2, 1}, {-1, -2}, {-1, 2}, {1, -2}, {1, 2}, {2, -1}, {2, 1}};
+    const int from = action_idx / 73, off = action_idx % 73;
+    const int fr = from >> 3, ff = from & 7;
+    int dr, df, steps = 1, promo = 0;
+    bool under = false;
+    if (off < 56) { dr = RAY[off / 7][0]; df = RAY[off / 7][1]; steps = off % 7 + 1; }
+    else if (off < 64) { dr = KN[off - 56][0]; df = KN[off - 56][1]; }
+    else {
+        const int u = off - 64, d = u % 3;
+        static const int DW[3][2] = {{1, 0}, {1, -1}, {1, 1}}, DB[3][2] = {{-1, 0}, {-1, 1}, {-1, -1}};
+        dr = p.turn == WHITE ? DW[d][0] : DB[d][0]; df = p.turn == WHITE ? DW[d][1] : DB[d][1];
+        promo = u / 3 + 1; under = true;
+    }
+    const int tr = fr + dr * steps, tf = ff + df * steps;
+    int to = -1;
+    Move want = 0xFFFF;
+    if (tr >= 0 && tr < 8 && tf >= 0 && tf < 8) {
+        to = tr * 8 + tf;
+        if (!under && piece_type_at(p, from) == PAWN && (p.occ[0] | p.occ[1]) & bit(from) && (tr == 0 || tr == 7)) promo = 4;
+        want = mk_move(from, to, promo);
+    }
+    Move pick = 0xFFFF;
+    for (int i = 0; i < n && pick == 0xFFFF; ++i) if (mv[i] == want) pick = mv[i];
+    if (to >= 0) for (int i = 0; i < n && pick == 0xFFFF; ++i) if (mv_from(mv[i]) == from && mv_to(mv[i]) == to) pick = mv[i];
+    if (to < 0) for (int i = 0; i < n && pick == 0xFFFF; ++i) if (mv_from(mv[i]) == from && mv_to(mv[i]) == 0) pick = mv[i];   // null move target a1 (python Move.null().to_square == 0)
+    for (int i = 0; i < n && pick == 0xFFFF; ++i) if (mv_from(mv[i]) == from) pick = mv[i];
+    if (pick == 0xFFFF) { strcpy(uci_out, "0000"); return M0_OK; }
+    const int f = mv_from(pick), t = mv_to(pick), pr = mv_promo(pick);
+    uci_out[0] = (char)('a' + (f & 7)); uci_out[1] = (char)('1' + (f >> 3));
+    uci_out[2] = (char)('a' + (t & 7)); uci_out[3] = (char)('1' + (t >> 3));
+    uci_out[4] = pr ? " nbrq"[pr] : '\0'; uci_out[5] = '\0';
+    return M0_OK;
+}
+
 // ---------------- host decision functions ----------------
 int m0_sample_move_index(const int32_t* visits, int n, double temperature, double u) {
     if (!visits || n <= 0) return -1;

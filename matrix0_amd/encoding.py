@@ -55,6 +55,14 @@ class MoveEncoder:
     def encode_move(self, fen: str, uci: str) -> int:
         return move_to_index(fen, uci)
 
+    def decode_move(self, fen: str, action_idx: int) -> str:
+        """encoding.py:174-229 -> UCI string ('0000' = Move.null())."""
+        if not (0 <= int(action_idx) < 4672):
+            raise ValueError("action_idx out of range")
+        buf = C.create_string_buffer(8)
+        _lib.check(_bind().m0_decode_move_fen(0, fen.encode(), int(action_idx), buf), "decode_move")
+        return buf.value.decode()
+
     def get_legal_actions(self, fen: str) -> np.ndarray:
         return encode_fens([fen], want_moves=False)[1][0]
 

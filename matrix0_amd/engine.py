@@ -71,6 +71,7 @@ def _bind():
     L.m0_search_advance.argtypes = [C.c_void_p, c_int, c_int, c_int, c_int]
     L.m0_encode_fens.argtypes = [c_int, C.POINTER(C.c_char_p), c_int] + [C.c_void_p] * 5
     L.m0_move_to_index_fen.argtypes = [c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int32)]
+    L.m0_decode_move_fen.argtypes = [c_int, C.c_char_p, c_int, C.c_char_p]
     L.m0_ssl_targets_fens.argtypes = [c_int, C.POINTER(C.c_char_p), c_int, C.c_void_p]
     L.m0_sample_move_index.argtypes = [C.c_void_p, c_int, c_double, c_double]
     L.m0_playout_cap.argtypes = [c_int, c_double, c_double]
@@ -93,6 +94,9 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     sp = dict(cfg.get("selfplay", {}) or {})
     draw = dict(cfg.get("draw", {}) or {})
     draw.update(sp.get("draw", {}) or {})
+    if int(m.get("max_children", 0) or 0) > 0 or float(m.get("min_child_prior", 0.0) or 0.0) > 0.0:
+        raise ValueError("mcts.max_children / mcts.min_child_prior (MCTS._prune_children, mcts.py:806-826) are not implemented "
+                         "in the MI355X engine; config.yaml ships them disabled (0 / 0.0)")
     c = SelfplayCfg()
     c.num_simulations = int(sp.get("num_simulations", m.get("num_simulations", 800)))
     c.cpuct = float(sp.get("cpuct", m.get("cpuct", 2.5)))

@@ -308,3 +308,47 @@ def legal_moves_with_indices(board: Board):
     idx = (C.c_int32 * 256)()
     n = board._l.o_legal_moves_idx(board._p, buf, idx)
     return [Move(buf[i].from_, buf[i].to, buf[i].promo or None) for i in range(n)], [int(idx[i]) for i in range(n)]
+
+
+RAY_DIRS = ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (1, -1), (-1, 1), (-1, -1))
+KNIGHT_DELTAS = ((-2, -1), (-2, 1), (-1, -2), (-1, 2), (1, -2), (1, 2), (2, -1), (2, 1))
+
+
+def decode_move(board: Board, action_idx: int) -> Move:
+    """MoveEncoder.decode_move, encoding.py:174-229: index -> Move with auto-queen on the last rank and the
+    same-destination / same-origin legal fallbacks; Move.null() when nothing fits."""
+    if not (0 <= action_idx < 4672):
+        raise ValueError("action_idx out of range")
+    from_sq, off = divmod(action_idx, 73)
+    fr, ff = from_sq >> 3, from_sq & 7
+
+    def mk(dr, df, steps=1, promo=None):
+        tr, tf = fr + dr * steps, ff + df * steps
+        if not (0 <= tr < 8 and 0 <= tf < 8):
+            return Move.null()
+        p = promo
+        if promo is None and board.piece_type_at(from_sq) == PAWN and tr in (0, 7):
+            p = QUEEN
+        return Move(from_sq, tr * 8 + tf, p)
+
+    if off < 56:
+        dr, df = RAY_DIRS[off // 7]
+        mv = mk(dr, df, off % 7 + 1)
+    elif off < 64:
+        dr, df = KNIGHT_DELTAS[off - 56]
+        mv = mk(dr, df)
+    else:
+        u = off - 64
+        dirs = ((1, 0), (1, -1), (1, 1)) if board.turn else ((-1, 0), (-1, 1), (-1, -1))
+        dr, df = dirs[u % 3]
+        mv = mk(dr, df, 1, (KNIGHT, BISHOP, ROOK)[u // 3])
+    legal = board.legal_moves
+    if mv in legal:
+        return mv
+    for lm in legal:
+        if lm.from_square == from_sq and lm.to_square == mv.to_square:
+            return lm
+    for lm in legal:
+        if lm.from_square == from_sq:
+            return lm
+    return Move.null()

@@ -75,3 +75,22 @@ def test_ssl_targets_on_device_match_reference_goldens_and_oracle():
         o = ssl_ref.targets(ch.encode_board(ch.Board(fen)))
         for k in ("piece", "threat", "pin", "fork", "control"):
             assert np.array_equal(t2[k][i], o[k].astype(np.float32)), (fen, k)
+
+
+def test_decode_move_roundtrip_and_fallbacks():
+    """MoveEncoder.decode_move (encoding.py:174-229): Kiwipete round trip (tests/test_encoding.py), then arbitrary
+    indices (illegal / off-board / under-promotion slots) against the oracle's restatement incl. the fallbacks."""
+    from matrix0_amd import encoding as enc
+    me = enc.MoveEncoder()
+    b = ch.Board(KIWIPETE)
+    for m, i in zip(*ch.legal_moves_with_indices(b)):
+        assert me.decode_move(KIWIPETE, i) == m.uci()
+    rng = np.random.default_rng(4)
+    rows = json.load(gzip.open(os.path.join(GOLDEN, "tactical_legal_counts.json.gz"), "rt"))
+    for fen, _, _ in rows[::500] + [["8/P7/8/8/8/8/8/4k2K w - - 0 1", 0, ""], ["8/8/8/8/8/8/p7/4K2k b - - 0 1", 0, ""]]:
+        bb = ch.Board(fen)
+        for idx in rng.integers(0, 4672, size=60):
+            want = ch.decode_move(bb, int(idx)).uci()
+            assert me.decode_move(fen, int(idx)) == want, (fen, int(idx))
+    with pytest.raises(ValueError):
+        me.decode_move(KIWIPETE, 4672)

@@ -136,3 +136,28 @@ def test_expand_priors_vs_reference_numerics(sharp, legal_softmax):
         want = ref.legal_priors(lg[0], idxs, legal_softmax, True, noise, numerics="reference")
         np.testing.assert_allclose(results[g]["prior"], want.astype(np.float64), rtol=0, atol=1e-6)
         assert abs(results[g]["prior"].sum() - 1.0) < 1e-5
+
+
+def test_c_base_cpuct_schedule_and_long_search():
+    """KataGo-style cpuct (mcts.py:929-934) and a 1600-simulation search with Dirichlet + virtual loss
+    (BASELINE configs[4] search shape) against the oracle."""
+    from matrix0_amd import engine as eng
+    G, L, sims = 2, 16, 1600
+    m = dict(MCTS, inference_batch_size=L, cpuct_c_base=19652.0, cpuct_c_init=1.25)
+    cfg = eng.selfplay_cfg_from_dict({"seed": 1234, "mcts": m, "selfplay": {"num_simulations": sims}}, concurrent_games=G)
+    assert cfg.use_c_base == 1
+    e = eng.SelfplayEngine(None, cfg)
+    net = FakeNet(seed=21, sharp=10.0)
+    for g in range(G):
+        e.search_begin(g, FENS[g], sims, True, 900 + g)
+    results = _run_engine_search(e, net, G)
+    for g in range(G):
+        o, b, vc, pi, rq = _oracle(FENS[g], 900 + g, sims, L, FakeNet(seed=21, sharp=10.0), m, True, True)
+        _compare(results[g], o, vc, rq)
+        assert sum(results[g]["n"]) == sims
+
+
+def test_unsupported_pruning_fails_loudly():
+    from matrix0_amd import engine as eng
+    with pytest.raises(ValueError, match="_prune_children"):
+        eng.selfplay_cfg_from_dict({"mcts": {"max_children": 8}}, concurrent_games=1)

@@ -125,3 +125,43 @@ def test_drop_in_worker_writes_shards_and_queue_messages(tmp_path):
         np.testing.assert_allclose(z["pi"].sum(axis=1), 1.0, atol=1e-3)
     n = sqlite3.connect(str(tmp_path / "data_metadata.db")).execute("SELECT count(*), sum(sample_count) FROM shards").fetchone()
     assert n[0] == 4 and n[1] == sum(m["moves"] for m in games)
+
+
+def test_baseline_config0_one_game_64_sims_full_size_net():
+    """BASELINE configs[0] as a parity case: 1 self-play game, 64 sims/move, random-init R24-320 (the reference's
+    CPU-runnable case), here on the GPU; the game is replayed through the oracle's rules and encoder."""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    from matrix0_amd.weights import random_state_dict
+    r24 = dict(planes=19, channels=320, blocks=24, attention_heads=20, policy_size=4672, norm="group", activation="silu",
+               preact=True, policy_factor_rank=128, self_supervised=True, ssl_tasks=["piece", "threat", "pin", "fork", "control"])
+    be = M0Backend.from_state_dict(r24, random_state_dict(r24, seed=0))
+    cfg_d = {"seed": 1234, "mcts": dict(CFG["mcts"], inference_batch_size=16),
+             "selfplay": dict(CFG["selfplay"], num_simulations=64, max_game_len=24, opening_random_plies=12)}
+    e = eng.SelfplayEngine(be, eng.selfplay_cfg_from_dict(cfg_d, concurrent_games=1, total_games=1, ssl_in_forward=True,
+                                                          ssl_targets=True))
+    g = None
+    while e.running():
+        e.step(16)
+        r = e.poll()
+        if r is not None:
+            g = r
+    assert g is not None and 1 <= g["moves"] <= 24
+    T = g["moves"]
+    b = ch.Board()
+    played = [ch.Move.from_uci(u) for u in g["played"]]
+    n_open = len(played) - (T - (1 if g["resigned"] else 0))
+    for i, mv in enumerate(played):
+        assert mv in b.legal_moves
+        if i >= n_open:
+            t = i - n_open
+            assert np.array_equal(g["s"][t], ch.encode_board(b))
+            assert np.array_equal(g["legal_mask"][t].astype(bool), ch.get_legal_actions(b))
+            from oracle import ssl_ref
+            tg = ssl_ref.targets(ch.encode_board(b))
+            for k in ("piece", "threat", "pin", "fork", "control"):
+                assert np.array_equal(g["ssl"][k][t], tg[k].astype(np.float32)), k
+        b.push(mv)
+    st = e.stats()
+    assert 64 * T * 0.9 <= st["sims"] <= 64 * T * 1.1 + 64      # playout cap +-5 %
+    np.testing.assert_allclose(g["pi"].sum(axis=1), 1.0, atol=1e-4)
