@@ -1,6 +1,7 @@
 // conv_big_kernel: the dominant kernel of the network forward (3x3 / 1x1 implicit-GEMM conv on MFMA with
 // global_load_lds staging and fused block epilogues).  See net_kernels.hip's header for the design.
 #include "kernel_common.h"
+#include "conv_epilogue.h"
 
 // ---------------------------------------------------------------------------
 // conv_big: the hot kernel (see file header)
@@ -183,85 +184,14 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
         });
     }
 
-    // ---------------- epilogue ----------------
-    const int ldo = a.ldo;
-    const int rowbase = m0 + wm * 64 + 4 * half;
-    const int colbase = n0 + wn * NT * 32 + r31;
-    if constexpr (EPI == 1) {
-        // GroupNorm(16 channels x 64 squares) + activation on the accumulators: this wave owns the whole group
-        const int act = a.epi_act;
-        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-            constexpr int ni = decltype(ni_)::value;
-            const int col = colbase + ni * 32;
-            float s = 0.f, ss = 0.f;
-            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-                const float16v av = acc[decltype(mi_)::value][ni];
-                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
-            });
-#pragma unroll
-            for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-            const float mean = s * (1.f / 1024.f);
-            float var = ss * (1.f / 1024.f) - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
-            const float sh = a.gn_beta[col] - mean * g;
-            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-                constexpr int mi = decltype(mi_)::value;
-                const float16v av = acc[mi][ni];
-                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
-                    constexpr int r = decltype(r_)::value;
-                    const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = act_apply(av[r] * g + sh, act);
-                    if (row < a.Mvalid) reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
-                });
-            });
-        });
-        return;
-    }
-    if constexpr (EPI == 0) {
-    const int epi_act = a.epi_act;
-    const float oscale = a.out_scale;
-    const bool has_mul = a.mul != nullptr;
-    const bool f32out = a.out_f32 != 0;
-    const bool want_stats = a.out_stats != nullptr;
-    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
-        constexpr int ni = decltype(ni_)::value;
-        const int col = colbase + ni * 32;
-        const float bias = a.bias != nullptr ? a.bias[col] : 0.f;
-        float s = 0.f, ss = 0.f;
-        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
-            constexpr int mi = decltype(mi_)::value;
-            const float16v av = acc[mi][ni];
-            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
-                constexpr int r = decltype(r_)::value;
-                const int row = rowbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                float v = av[r] + bias;
-                if (epi_act != ACT_NONE) v = act_apply(v, epi_act);
-                if (has_mul) v *= (float)a.mul[(size_t)row * ldo + col];
-                v *= oscale;
-                s += v; ss += v * v;
-                if (row < a.Mvalid) {
-                    if (f32out) reinterpret_cast<float*>(a.out)[(size_t)row * ldo + col] = v;
-                    else reinterpret_cast<_Float16*>(a.out)[(size_t)row * ldo + col] = (_Float16)v;
-                }
-            });
-        });
-        if (want_stats) {
-            s += __shfl_xor(s, 32);
-            ss += __shfl_xor(ss, 32);
-            if (lane < 32) {
-                float* st = a.out_stats + ((size_t)(m0 / 64 + wm) * a.N + col) * 2;
-                st[0] = s; st[1] = ss;
-            }
-        }
-    });
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                      // the epilogue stages the output tile over the A/W buffers
+    conv_tile_epilogue<EPI, ACT_NONE, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
 }
 
 template <int TAPS, int EPI, int WNW>
 static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = 2 * 256 * 128 + 2 * 320 * 128 + 128;
+    const size_t lds = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW>),
@@ -275,10 +205,11 @@ static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
+    // 1x1 convs whose N is a multiple of 320 (qkv, proj).  3x3: conv_pp_kernel (conv_pp.hip).
     // WNW = 2 (8 waves).  The 4-wave / 512-register form (WNW = 1) was built and measured: numerically identical,
     // 2x slower with hipcc's schedule (LDS latency exposed with one wave per SIMD, spills) -- not instantiated.
-    const bool gn = a.gn_gamma != nullptr;
-    if (taps == 9) return gn ? launch_conv_big_e<9, 1, 2>(a, st) : launch_conv_big_e<9, 0, 2>(a, st);
-    if (taps == 1) return gn ? hipErrorInvalidValue : launch_conv_big_e<1, 0, 2>(a, st);
-    return hipErrorInvalidValue;
+    if (taps != 1 || a.gn_gamma != nullptr) return hipErrorInvalidValue;
+    if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
+    const bool general = a.mul != nullptr || a.out_f32 != 0 || a.epi_act != ACT_NONE;   // per-element epilogue
+    return general ? launch_conv_big_e<1, 2, 2>(a, st) : launch_conv_big_e<1, 0, 2>(a, st);
 }

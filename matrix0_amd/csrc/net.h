@@ -20,6 +20,7 @@ struct PackedGemm {
     _Float16* w = nullptr;   // [taps][Cin/KC][N][KC]
     float* bias = nullptr;   // [N] or null
     int taps = 1, Cin = 0, N = 0;
+    bool pp = false;         // 3x3 big tile in conv_pp_kernel's layout [chunk*9+tap][N/320][k half][320][32]
 };
 
 struct NormParams {

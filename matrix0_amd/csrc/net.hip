@@ -107,6 +107,8 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     nparams_ += expect;
     const int KC = conv_gemm_kc(Cin_pad, N_pad);
     const int nchunk = Cin_pad / KC;
+    const bool pp = KC == 64 && taps == 9;       // 3x3 big tile: conv_pp_kernel's half-tile layout
+    const int nblk = N_pad / 320;
     std::vector<_Float16> p((size_t)taps * Cin_pad * N_pad, (_Float16)0.f);
     for (int n = 0; n < N_real; ++n)
         for (int k = 0; k < Cin_real; ++k)
@@ -118,6 +120,12 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
                     kk = sq * k_perm_ch + c;
                 }
                 int chunk = kk / KC, kc = kk % KC;
+                if (pp) {       // conv_pp_kernel: half-K-tiles of 320 x 32 k, 64-byte rows, chunk ^ (row>>2)&3
+                    const int kt = chunk * 9 + t, by = n / 320, nl = n % 320, h = kc >> 5, k32 = kc & 31;
+                    const int kx = (((k32 >> 3) ^ ((nl >> 2) & 3)) << 3) | (k32 & 7);
+                    p[((((size_t)kt * nblk + by) * 2 + h) * 320 + nl) * 32 + kx] = (_Float16)v;
+                    continue;
+                }
                 if (KC == 64)   // big tile: LDS image order, 16-byte chunk index XOR (row>>1)&7 (conv_big_kernel)
                     kc = (((kc >> 3) ^ ((n >> 1) & 7)) << 3) | (kc & 7);
                 p[(((size_t)t * nchunk + chunk) * N_pad + n) * KC + kc] = (_Float16)v;
@@ -125,7 +133,7 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     g.w = (_Float16*)dalloc(p.size() * 2, false);
     if (!g.w) { err = "hipMalloc failed"; return M0_ERR_HIP; }
     (void)hipMemcpy(g.w, p.data(), p.size() * 2, hipMemcpyHostToDevice);
-    g.taps = taps; g.Cin = Cin_pad; g.N = N_pad;
+    g.taps = taps; g.Cin = Cin_pad; g.N = N_pad; g.pp = pp;
     g.bias = nullptr;
     if (!bkey.empty()) {
         const HostTensor* b = get(bkey, err);
@@ -364,7 +372,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     a.gn_beta = out_norm ? out_norm->beta : nullptr;
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
-    a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale;
+    a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale; a.w_pp = g.pp ? 1 : 0;
     const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {

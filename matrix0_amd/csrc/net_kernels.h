@@ -23,6 +23,7 @@ struct GemmArgs {
     int epi_act;
     int out_f32;
     float out_scale;
+    int w_pp;                // 3x3 big tile: w is in conv_pp_kernel's half-tile layout (pack_gemm)
 };
 
 struct EwArgs {
