@@ -22,7 +22,7 @@ static const int kSslOut[5] = {13, 1, 1, 1, 3};
 const char* Net::check_supported(const m0_net_cfg& c) {
     if (!c.norm_group) return "HIP path supports norm='group' only (BatchNorm configs are not built)";
     if (!c.preact) return "HIP path supports preact=true only";
-    if (c.channels % 32 != 0 || c.channels < 32 || c.channels > 512) return "channels must be a multiple of 32 in [32,512]";
+    if (c.channels % 32 != 0 || c.channels < 32 || c.channels > 384) return "channels must be a multiple of 32 in [32,384]";
     if (c.planes < 1 || c.planes > 32) return "planes must be in [1,32]";
     if (c.attention && (c.attention_heads <= 0 || c.channels % c.attention_heads != 0 ||
                         c.channels / c.attention_heads != 16))
@@ -345,7 +345,7 @@ int Net::ensure_workspace(int B, std::string& err) {
     X0_ = H(nb * 64 * 32);
     XA_ = H(nb * 64 * C); XB_ = H(nb * 64 * C); T1_ = H(nb * 64 * C); T2_ = H(nb * 64 * C); AA_ = H(nb * 64 * C);
     QKV_ = H(nb * 64 * 3 * C); O_ = H(nb * 64 * C);
-    SX_ = F(nb * Cst * 2); S1_ = F(nb * Cst * 2); S2_ = F(nb * Cst * 2);
+    SX_ = F(nb * Cst * 2); S1_ = F(nb * Cst * 2); S2_ = F(nb * Cst * 2); G_ = F(nb * Cst);
     PH_ = H(nh * 64 * 64); PH2_ = H(nh * 64 * 64);
     VH_ = H(nh * 64 * 128); VH2_ = H(nh * 64 * 128);
     const size_t rp = cfg_.policy_factor_rank > 0 ? ceil_to(cfg_.policy_factor_rank, 32) : 32;
@@ -436,7 +436,14 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         memset(&e, 0, sizeof(e));
         e.t = t; e.t_stats = tst;
         if (gn) { e.gn_gamma = gn->gamma; e.gn_beta = gn->beta; }
-        if (se) { e.se_w1 = se->se_w1; e.se_b1 = se->se_b1; e.se_w2 = se->se_w2; e.se_b2 = se->se_b2; e.se_hidden = se->se_hidden; }
+        if (se) {
+            SeGateArgs g;
+            g.t_stats = tst; g.w1 = se->se_w1; g.b1 = se->se_b1; g.w2 = se->se_w2; g.b2 = se->se_b2;
+            g.gate = G_; g.B = boards; g.C = Cc; g.hidden = se->se_hidden; g.act = act;
+            hipError_t ge = launch_se_gate(g, st);
+            if (ge != hipSuccess) return ge;
+            e.gate = G_;
+        }
         e.res = res; e.posenc = pos;
         if (ln) { e.ln_g = ln->gamma; e.ln_b = ln->beta; }
         e.y = y; e.out_stats = ost; e.C = Cc; e.act = act; e.stats_from_rounded = 0;

@@ -31,10 +31,7 @@ struct EwArgs {
     const float* t_stats;    // [B][C][2]
     const float* gn_gamma;   // GroupNorm16 + act when non-null
     const float* gn_beta;
-    const float* se_w1;      // [C][Hd] (transposed), SE gate when non-null (and gn null)
-    const float* se_b1;
-    const float* se_w2;      // [Hd][C] (transposed)
-    const float* se_b2;
+    const float* gate;       // [B][C] squeeze-excite gate (se_gate_kernel), applied when non-null (and gn null)
     const _Float16* res;     // [B][64][C] or null
     const float* posenc;     // [64][C] or null
     const float* ln_g;       // LayerNorm over C when non-null
@@ -45,9 +42,18 @@ struct EwArgs {
     const float* gn2_gamma;
     const float* gn2_beta;
     int C;
-    int se_hidden;
     int act;
     int stats_from_rounded;
+};
+
+struct SeGateArgs {
+    const float* t_stats;    // [B][C][2] per-(board, channel) (sum, sumsq) over the 64 squares (conv epilogue)
+    const float* w1;         // [C][Hd] (transposed)
+    const float* b1;         // [Hd]
+    const float* w2;         // [Hd][C] (transposed)
+    const float* b2;         // [C]
+    float* gate;             // [B][C]
+    int B, C, hidden, act;
 };
 
 struct AttnArgs {
@@ -64,6 +70,7 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st);
 int conv_gemm_tile_n(int Cin, int Npad);
 int conv_gemm_kc(int Cin, int Npad);
 hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st);
+hipError_t launch_se_gate(const SeGateArgs& a, hipStream_t st);
 hipError_t launch_attn_core(const AttnArgs& a, hipStream_t st);
 hipError_t launch_planes_to_nhwc(const float* x, void* y, int B, int P, hipStream_t st);
 hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int B, int ld, int n, int ctot, int coff, hipStream_t st);

@@ -253,34 +253,61 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
-// ew_board: one workgroup (256 threads) per board, tensor [64][C] fp16, the board held in registers.
+// ew_board: one workgroup per board, tensor [64][C] fp16.
 //   v = t
 //   if gn_gamma: v = act(GroupNorm16(v))             (statistics from t_stats)
-//   elif se_w1:  v *= gate[c]   gate = sigmoid(W2 act(W1 pool + b1) + b2), pool from t_stats sums
+//   elif gate:   v *= gate[b][c]                     (squeeze-excite, se_gate_kernel)
 //   if res:      v += res
 //   if posenc:   v += posenc[n][c]
 //   if ln_g:     v = LayerNorm_C(v)
 //   y = v                                             (the raw residual stream)
 //   out_stats = per-channel (sum, sumsq) of y over the 64 squares
 //   if y2: y2 = act(GroupNorm16(y; gn2_gamma, gn2_beta))   -- the pre-activation input of the next block's conv1
+//
+// Memory-bound (4 x 40 KB per board at C = 320) and, per board, a chain of dependent steps (statistics -> gate MLP ->
+// values -> statistics -> second output), so what decides the speed is how many bytes a CU keeps in flight:
+// 2C threads, thread = (8-channel chunk, group of 4 squares); every thread issues ALL its tensor loads (4 squares x
+// {t, res} x 16 B) before anything else, the gate / GroupNorm parameters are computed while they fly, the board's
+// values stay packed in registers for the second output (no re-read), every lane is live, every reduction has a fixed
+// order (bit-reproducible).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
-    // 8 waves; wave w owns squares w, w+8, ... (8 squares); lane l < C/8 owns channels 8l..8l+7 of each
-    // (one 16-byte load/store per square).  Memory-bound: ~4 x 40 KB per board at C = 320.
+__global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = a.C;
+    const int C = a.C, NC = C >> 3;
     float* sc = reinterpret_cast<float*>(smem);        // [C] scale (GN) or gate (SE); later GN2 scale
     float* sh = sc + C;                                // [C] shift / pooled mean
-    float* red = sh + C;                               // [8 waves][C][2] stats partials (also SE partials)
-    float* tot = red + 8 * C * 2;                      // [C][2]
-    float* hid = tot + 2 * C;                          // [hidden]
+    float* tot = sh + C;                               // [C][2]
+    float* rowbuf = tot + 2 * C;                       // [64][2] LayerNorm (mean, rstd) per square
+    float* red = rowbuf + 128;                            // [16][C][2] stats partials; SE partials; LN partials [64][NC][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nw = nthr >> 6;       // 16 * NC threads
+    const int chunk = tid % NC, sg = tid / NC;         // squares 4 sg .. 4 sg + 3
+    const int c0 = chunk * 8;
     const int b = blockIdx.x;
-    const _Float16* t = a.t + (size_t)b * 64 * C;
+    const _Float16* t = a.t + (size_t)b * 64 * C + (size_t)(sg * 4) * C + c0;
+    const _Float16* res = a.res ? a.res + (size_t)b * 64 * C + (size_t)(sg * 4) * C + c0 : nullptr;
     const float* tst = a.t_stats ? a.t_stats + (size_t)b * C * 2 : nullptr;
 
-    if (a.gn_gamma != nullptr) {
-        for (int c = tid; c < C; c += 512) {
+    // 1. all tensor loads first
+    const bool gn = a.gn_gamma != nullptr;
+    const bool se = (!gn) && a.gate != nullptr;
+    float gatev[8];
+    {
+        const float4 g0 = se ? *reinterpret_cast<const float4*>(a.gate + (size_t)b * C + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 g1 = se ? *reinterpret_cast<const float4*>(a.gate + (size_t)b * C + c0 + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        gatev[0] = g0.x; gatev[1] = g0.y; gatev[2] = g0.z; gatev[3] = g0.w;
+        gatev[4] = g1.x; gatev[5] = g1.y; gatev[6] = g1.z; gatev[7] = g1.w;
+    }
+    half8 tv[4], rv[4];
+    static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_)::value;
+        tv[k] = *reinterpret_cast<const half8*>(t + k * C);
+        rv[k] = res ? *reinterpret_cast<const half8*>(res + k * C) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    });
+
+    // 2. per-channel scale / shift
+    if (gn) {
+        for (int c = tid; c < C; c += nthr) {
             const int g0 = (c >> 4) << 4;
             float s = 0.f, ss = 0.f;
             for (int j = 0; j < 16; ++j) { s += tst[2 * (g0 + j)]; ss += tst[2 * (g0 + j) + 1]; }
@@ -291,97 +318,93 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
             sc[c] = g;
             sh[c] = a.gn_beta[c] - mean * g;
         }
-    } else if (a.se_w1 != nullptr) {
-        // squeeze-excite gate (resnet.py:59-68); pooled mean from the conv epilogue sums
-        const int Hd = a.se_hidden;
-        for (int c = tid; c < C; c += 512) sh[c] = tst[2 * c] * (1.f / 64.f);
-        __syncthreads();
-        // hidden = act(W1 pool + b1): wave w sums channels [w*C/8, (w+1)*C/8), lanes over hidden units
-        const int cs = (C + 7) / 8;
-        for (int j = lane; j < Hd; j += 64) {
-            float s = 0.f;
-            const int c1 = (wave + 1) * cs < C ? (wave + 1) * cs : C;
-            for (int c = wave * cs; c < c1; ++c) s += a.se_w1[(size_t)c * Hd + j] * sh[c];   // w1 stored [C][Hd]
-            red[wave * Hd + j] = s;
-        }
-        __syncthreads();
-        for (int j = tid; j < Hd; j += 512) {
-            float s = a.se_b1[j];
-            for (int w = 0; w < 8; ++w) s += red[w * Hd + j];
-            hid[j] = act_apply(s, a.act);
-        }
-        __syncthreads();
-        for (int c = tid; c < C; c += 512) {
-            float s = a.se_b2[c];
-            for (int j = 0; j < Hd; ++j) s += a.se_w2[(size_t)j * C + c] * hid[j];          // w2 stored [Hd][C]
-            sc[c] = 1.f / (1.f + __expf(-s));
-        }
     }
     __syncthreads();
 
-    const bool gn = a.gn_gamma != nullptr;
-    const bool se = (!gn) && a.se_w1 != nullptr;
-    const _Float16* res = a.res ? a.res + (size_t)b * 64 * C : nullptr;
-    _Float16* y = a.y + (size_t)b * 64 * C;
-    const int c0 = lane * 8;
-    const bool live = c0 < C;
-    float csum[8], csq[8];
-    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+    // 3. values
     float scl[8], shl[8];
     static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
         constexpr int i = decltype(i_)::value;
-        scl[i] = (live && (gn || se)) ? sc[c0 + i] : 1.f;
-        shl[i] = (live && gn) ? sh[c0 + i] : 0.f;
+        scl[i] = gn ? sc[c0 + i] : gatev[i];
+        shl[i] = gn ? sh[c0 + i] : 0.f;
     });
-    for (int k = 0; k < 8; ++k) {
-        const int n = wave + 8 * k;
-        float rs = 0.f, rss = 0.f;
-        half8 tv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (live) {
-            tv = *reinterpret_cast<const half8*>(t + n * C + c0);
-            if (res) rv = *reinterpret_cast<const half8*>(res + n * C + c0);
-        }
-        float v[8];
+    float x[4][8];
+    static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_)::value;
         static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
-            float x = (float)tv[i];
-            if (gn) x = act_apply(x * scl[i] + shl[i], a.act);
-            else if (se) x *= scl[i];
-            x += (float)rv[i];
-            if (a.posenc && live) x += a.posenc[n * C + c0 + i];
-            if (!live) x = 0.f;
-            v[i] = x; rs += x; rss += x * x;
+            float v = (float)tv[k][i];
+            if (gn) v = act_apply(v * scl[i] + shl[i], a.act);
+            else if (se) v *= scl[i];
+            v += (float)rv[k][i];
+            if (a.posenc) v += a.posenc[(sg * 4 + k) * C + c0 + i];
+            x[k][i] = v;
         });
-        if (a.ln_g != nullptr) {
-            for (int o = 32; o > 0; o >>= 1) { rs += __shfl_xor(rs, o); rss += __shfl_xor(rss, o); }
-            const float mean = rs / (float)C;
-            float var = rss / (float)C - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            const float rstd = rsqrtf(var + 1e-5f);
+    });
+    if (a.ln_g != nullptr) {
+        // LayerNorm over C per square: partial sums per (square, chunk) -> 8 threads per square -> (mean, rstd)
+        float2* part = reinterpret_cast<float2*>(red);          // [64][NC]
+        static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            float rs = 0.f, rss = 0.f;
+            static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { const float v = x[k][decltype(i_)::value]; rs += v; rss += v * v; });
+            part[(sg * 4 + k) * NC + chunk] = make_float2(rs, rss);
+        });
+        __syncthreads();
+        float2* rowp = reinterpret_cast<float2*>(rowbuf);        // [64] (mean, rstd)
+        for (int u = tid; u < 512; u += nthr) {                  // 8 consecutive lanes per square
+            const int sq = u >> 3, p8 = u & 7;
+            float rs = 0.f, rss = 0.f;
+            for (int ch = p8; ch < NC; ch += 8) { const float2 v = part[sq * NC + ch]; rs += v.x; rss += v.y; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { rs += __shfl_xor(rs, o); rss += __shfl_xor(rss, o); }
+            if (p8 == 0) {
+                const float mean = rs / (float)C;
+                float var = rss / (float)C - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                rowp[sq] = make_float2(mean, rsqrtf(var + 1e-5f));
+            }
+        }
+        __syncthreads();
+        float lg[8], lb[8];
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value;
+            lg[i] = a.ln_g[c0 + i]; lb[i] = a.ln_b[c0 + i];
+        });
+        static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            const float2 mr = rowp[sg * 4 + k];
             static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_)::value;
-                if (live) v[i] = (v[i] - mean) * rstd * a.ln_g[c0 + i] + a.ln_b[c0 + i];
+                x[k][i] = (x[k][i] - mr.x) * mr.y * lg[i] + lb[i];
             });
-        }
-        half8 ov;
+        });
+        __syncthreads();                                         // part (red) is reused below
+    }
+
+    // 4. first output + per-channel statistics
+    _Float16* y = a.y + (size_t)b * 64 * C + (size_t)(sg * 4) * C + c0;
+    half8 yv[4];
+    float csum[8], csq[8];
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+    static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_)::value;
         static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
-            ov[i] = (_Float16)v[i];
-            csum[i] += v[i]; csq[i] += v[i] * v[i];
+            yv[k][i] = (_Float16)x[k][i];
+            csum[i] += x[k][i]; csq[i] += x[k][i] * x[k][i];
         });
-        if (live) *reinterpret_cast<half8*>(y + n * C + c0) = ov;
-    }
+        *reinterpret_cast<half8*>(y + k * C) = yv[k];
+    });
     if (a.out_stats == nullptr && a.y2 == nullptr) return;
-    if (live) {
-        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_)::value;
-            red[(wave * C + c0 + i) * 2] = csum[i]; red[(wave * C + c0 + i) * 2 + 1] = csq[i];
-        });
-    }
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        reinterpret_cast<float2*>(red)[sg * C + c0 + i] = make_float2(csum[i], csq[i]);
+    });
     __syncthreads();
-    for (int c = tid; c < C; c += 512) {
+    for (int c = tid; c < C; c += nthr) {
         float s = 0.f, ss = 0.f;
-        for (int w = 0; w < 8; ++w) { s += red[(w * C + c) * 2]; ss += red[(w * C + c) * 2 + 1]; }
+        for (int g = 0; g < 16; ++g) { const float2 v = reinterpret_cast<const float2*>(red)[g * C + c]; s += v.x; ss += v.y; }
         tot[2 * c] = s; tot[2 * c + 1] = ss;
         if (a.out_stats != nullptr) {
             a.out_stats[((size_t)b * C + c) * 2] = s;
@@ -390,7 +413,8 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
     }
     if (a.y2 == nullptr) return;
     __syncthreads();
-    for (int c = tid; c < C; c += 512) {
+    // 5. second output from the register copy of y
+    for (int c = tid; c < C; c += nthr) {
         const int g0 = (c >> 4) << 4;
         float s = 0.f, ss = 0.f;
         for (int j = 0; j < 16; ++j) { s += tot[2 * (g0 + j)]; ss += tot[2 * (g0 + j) + 1]; }
@@ -402,29 +426,99 @@ __global__ __launch_bounds__(512, 6) void ew_board_kernel(EwArgs a) {
         sh[c] = a.gn2_beta[c] - mean * g;
     }
     __syncthreads();
-    if (!live) return;
-    _Float16* y2 = a.y2 + (size_t)b * 64 * C;
+    _Float16* y2 = a.y2 + (size_t)b * 64 * C + (size_t)(sg * 4) * C + c0;
     static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { constexpr int i = decltype(i_)::value; scl[i] = sc[c0 + i]; shl[i] = sh[c0 + i]; });
-    // second output from the values this very thread has just stored (L2-hot; keeps the kernel at ~50 VGPRs so
-    // several boards overlap per CU instead of holding the whole board in registers)
-    for (int k = 0; k < 8; ++k) {
-        const int n = wave + 8 * k;
-        const half8 yv = *reinterpret_cast<const half8*>(y + n * C + c0);
+    static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+        constexpr int k = decltype(k_)::value;
         half8 ov;
         static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
-            ov[i] = (_Float16)act_apply((float)yv[i] * scl[i] + shl[i], a.act);
+            ov[i] = (_Float16)act_apply((float)yv[k][i] * scl[i] + shl[i], a.act);
         });
-        *reinterpret_cast<half8*>(y2 + n * C + c0) = ov;
-    }
+        *reinterpret_cast<half8*>(y2 + k * C) = ov;
+    });
 }
 
 hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st) {
-    if (a.C > 512 || a.C % 8 != 0) return hipErrorInvalidValue;
-    const int hd = a.se_hidden > 0 ? a.se_hidden : 1;
-    size_t redsz = (size_t)16 * a.C > (size_t)8 * hd ? (size_t)16 * a.C : (size_t)8 * hd;
-    size_t lds = (size_t)(2 * a.C + redsz + 2 * a.C + hd) * 4;
-    hipLaunchKernelGGL(ew_board_kernel, dim3(boards), dim3(512), lds, st, a);
+    if (a.C > 384 || a.C % 32 != 0) return hipErrorInvalidValue;
+    const int nthr = 2 * a.C;                           // (C/8 chunks) x 16 square groups
+    const size_t lds = (size_t)(4 * a.C + 128 + 32 * a.C) * 4;
+    hipLaunchKernelGGL(ew_board_kernel, dim3(boards), dim3(nthr), lds, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// se_gate: squeeze-excite gate of every board (resnet.py:59-68), gate = sigmoid(W2 act(W1 pool + b1) + b2) with
+// pool = per-channel mean over the 64 squares, taken from the conv epilogue's sums.  One workgroup = 8 boards, C
+// threads.  The gate is a chain of dependent global-memory latencies, so it runs here, once, with every weight
+// fetched in batches of 16 independent loads and used for 8 boards, instead of inside each board's ew_board
+// workgroup (measured there: +100 us per call).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(384) void se_gate_kernel(SeGateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C, Hd = a.hidden;
+    float* pool = reinterpret_cast<float*>(smem);       // [8][C]
+    float* part = pool + 8 * C;                         // [parts][8][Hd]
+    float* hid = part + 8 * C;                          // [8][Hd]   (parts * Hd <= C)
+    const int tid = threadIdx.x, nthr = blockDim.x;     // == C
+    const int b0 = blockIdx.x * 8;
+    const int nb = a.B - b0 < 8 ? a.B - b0 : 8;
+    for (int q = 0; q < 8; ++q)
+        pool[q * C + tid] = q < nb ? a.t_stats[((size_t)(b0 + q) * C + tid) * 2] * (1.f / 64.f) : 0.f;
+    __syncthreads();
+    const int parts = nthr / Hd;                        // >= 1 (launcher)
+    {
+        const int j = tid % Hd, p = tid / Hd;
+        if (p < parts) {
+            const int cpp = (C + parts - 1) / parts;
+            const int cbeg = p * cpp, cend = cbeg + cpp < C ? cbeg + cpp : C;
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int cb = cbeg; cb < cend; cb += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = cb + u < cend ? a.w1[(size_t)(cb + u) * Hd + j] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = cb + u < cend ? cb + u : cbeg;      // w[u] == 0 past the end
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s[q] += w[u] * pool[q * C + c];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[(p * 8 + q) * Hd + j] = s[q];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * Hd; i += nthr) {
+        const int q = i / Hd, j = i - q * Hd;
+        float s = a.b1[j];
+        for (int p = 0; p < parts; ++p) s += part[(p * 8 + q) * Hd + j];
+        hid[q * Hd + j] = act_apply(s, a.act);
+    }
+    __syncthreads();
+    {
+        const int c = tid;
+        const float bias = a.b2[c];
+        float s[8] = {bias, bias, bias, bias, bias, bias, bias, bias};
+        for (int jb = 0; jb < Hd; jb += 16) {
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = jb + u < Hd ? a.w2[(size_t)(jb + u) * C + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = jb + u < Hd ? jb + u : 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s[q] += w[u] * hid[q * Hd + j];
+            }
+        }
+        for (int q = 0; q < nb; ++q) a.gate[(size_t)(b0 + q) * C + c] = 1.f / (1.f + __expf(-s[q]));
+    }
+}
+
+hipError_t launch_se_gate(const SeGateArgs& a, hipStream_t st) {
+    if (a.C > 384 || a.C % 32 != 0 || a.hidden < 1 || a.hidden > a.C) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(8 * a.C + 8 * a.C + 8 * a.hidden) * 4;
+    hipLaunchKernelGGL(se_gate_kernel, dim3((a.B + 7) / 8), dim3(a.C), lds, st, a);
     return hipGetLastError();
 }
 
