@@ -233,7 +233,11 @@ int Net::finalize(std::string& err) {
                 const HostTensor* rb = get(p + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
                 if ((int)rb->data.size() != cfg_.attention_heads * 4096) { err = "shape mismatch for rel_bias"; return M0_ERR_INVALID; }
                 nparams_ += rb->data.size();
-                a.rel_bias = upload_f32(rb->data);
+                {   // stored pre-multiplied by log2(e): the attention kernel exponentiates with exp2
+                    std::vector<float> rbs(rb->data);
+                    for (float& v : rbs) v *= 1.44269504088896f;
+                    a.rel_bias = upload_f32(rbs);
+                }
             }
         }
     }

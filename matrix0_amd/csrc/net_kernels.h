@@ -58,7 +58,7 @@ struct SeGateArgs {
 
 struct AttnArgs {
     const _Float16* qkv;     // [B][64][3C]
-    const float* rel_bias;   // [H][64][64] or null
+    const float* rel_bias;   // [H][64][64] * log2(e), or null
     const uint64_t* mask;    // [64] bit j of word i = key j visible from query i
     _Float16* o;             // [B][64][C]
     int B, H, C;

@@ -525,29 +525,55 @@ hipError_t launch_se_gate(const SeGateArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // attn_core: ChessAttention.forward lines 142-179 for one (board, head) per wave.
 // qkv [B][64][3C] fp16, channel = (t*H + h)*D + d, D == 16.  Lane = query square.
-//   S = QK^T/sqrt(D) (+rel_bias[h]) clamp +-50 ; masked branch fill -1e4 ;
+//   S = QK^T/sqrt(D) (+rel_bias[h]) clamp +-50 ; masked branch fill -1e4 ;   (rel_bias arrives times log2 e)
 //   out = (1-mix)*softmax(S_masked)V + mix*softmax(S)V     (mix in (0,1))
 //   mix >= 1: masked only ; mix <= 0: unmasked only.
 // o [B][64][C] fp16 with channel h*D+d.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void attn_core_kernel(AttnArgs a) {
-    // One wave per (board, head).  S^T = K Q^T on MFMA (32x32x16, K = head_dim = 16: one MFMA per 32x32 tile,
-    // operands straight from global memory), so a lane owns one query (column) and its keys sit in registers:
-    // the softmax sums over keys need a single cross-half shuffle.  PV on the VALU with V rows broadcast from LDS.
-    __shared__ __attribute__((aligned(16))) float Vs[4][64][16];
+#define ATT_BOARDS 16
+__global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
+    // One wave per (board, head), both matrix products on MFMA 32x32x16:
+    //   S^T = K Q^T  (A = K rows = keys, B = Q^T cols = queries; K = head_dim = 16: one MFMA per 32x32 tile, operands
+    //                 straight from global memory) -> a lane owns one query column and 16 keys per tile in registers,
+    //                 so the softmax sums need a single cross-half shuffle;
+    //   O^T = V^T P^T (A = V^T rows = head dims (16 of the 32 used), B = P^T cols = queries): the B operand IS the
+    //                 lane's register block of probabilities -- the contraction index may be enumerated in any order as
+    //                 long as A agrees, so A is gathered from a transposed LDS copy of V in the accumulator's key order.
+    // The first version did PV on the VALU (1024 FMAs + 256 LDS reads per lane and job): 520 us per call, VALU-bound;
+    // the second read rel_bias from global memory per job (32 KB per job, 2.7 GB per call through L2): 311 us.
+    // Workgroup = 4 waves = 4 consecutive heads (they share the 128-byte lines of a qkv row), looping over
+    // ATT_BOARDS boards (3 workgroups per CU at 154 VGPRs); the 4 heads' relative-position bias sits in LDS (fp16, pre-scaled) for all of them.
+    constexpr int VROW = 68;                           // halfs per LDS row (64 keys + pad: 136 B, conflict-free b64 reads)
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[4][16][VROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[4][64][VROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, C = a.C;
-    const long job = (long)blockIdx.x * 4 + wave;
-    const long njobs = (long)a.B * H;
-    const bool live = job < njobs;
-    const int b = live ? (int)(job / H) : 0, h = live ? (int)(job % H) : 0;
-    const _Float16* base = a.qkv + (size_t)b * 64 * 3 * C;
+    const int hgroups = (H + 3) >> 2;
+    const int hg = blockIdx.x % hgroups, bgroup = blockIdx.x / hgroups;
+    const int h = hg * 4 + wave;
+    const bool hlive = h < H;
     const int r31 = lane & 31, half = lane >> 5;
-    {   // V row `lane` -> LDS as fp32
+    if (a.rel_bias != nullptr) {
+        for (int i = tid; i < 4 * 64 * 16; i += 256) {             // 4 keys per item
+            const int hh = i >> 10, q = (i >> 4) & 63, k4 = (i & 15) * 4;
+            if (hg * 4 + hh < H) {
+                const float4 v = *reinterpret_cast<const float4*>(a.rel_bias + ((size_t)(hg * 4 + hh) * 64 + q) * 64 + k4);
+                typedef _Float16 half4s __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<half4s*>(&Bs[hh][q][k4]) = half4s{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            }
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < ATT_BOARDS; ++it) {
+    const int b = bgroup * ATT_BOARDS + it;
+    const bool live = hlive && b < a.B;
+    if (!live) continue;                               // wave-uniform; no barriers below
+    const _Float16* base = a.qkv + (size_t)b * 64 * 3 * C;
+    {   // V row `lane` (key) -> Vt[d][key]
         const _Float16* vp = base + (size_t)lane * 3 * C + (2 * H + h) * 16;
         const half8 v0 = *reinterpret_cast<const half8*>(vp), v1 = *reinterpret_cast<const half8*>(vp + 8);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) { Vs[wave][lane][d] = (float)v0[d]; Vs[wave][lane][8 + d] = (float)v1[d]; }
+        for (int d = 0; d < 8; ++d) { Vt[wave][d][lane] = v0[d]; Vt[wave][8 + d][lane] = v1[d]; }
     }
     // MFMA operands: A = K (rows = keys), B = Q^T (cols = queries); lane holds 8 consecutive head dims
     half8 kf[2], qf[2];
@@ -557,82 +583,100 @@ __global__ __launch_bounds__(256, 4) void attn_core_kernel(AttnArgs a) {
         qf[t] = *reinterpret_cast<const half8*>(base + (size_t)(t * 32 + r31) * 3 * C + (0 * H + h) * 16 + 8 * half);
     }
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // Vt[wave] is private to this wave: its LDS writes and reads execute in program order, no barrier
+    // A operand of the PV product for S^T tile kt, register block jb (regs 8jb..8jb+7): V[key][d], d = lane & 15,
+    // keys kt*32 + 16 jb + 4 half + {0..3} and + 8 more (the accumulator's row order)
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    half8 vf[2][2];
+    {
+        const _Float16* vrow = &Vt[wave][lane & 15][0];
+        static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+            static_for<0, 2>([&](auto jb_) __attribute__((always_inline)) {
+                constexpr int kt = decltype(kt_)::value, jb = decltype(jb_)::value;
+                const half4v lo = *reinterpret_cast<const half4v*>(vrow + kt * 32 + 16 * jb + 4 * half);
+                const half4v hi = *reinterpret_cast<const half4v*>(vrow + kt * 32 + 16 * jb + 8 + 4 * half);
+                vf[kt][jb] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            });
+        });
+    }
     float wm_, wu_;   // output weights of the masked / unmasked branch (resnet.py:154-174)
     if (a.mix > 0.f && a.mix < 1.f) { wm_ = 1.f - a.mix; wu_ = 1.f - (1.f - a.mix); }
     else if (a.mix >= 1.f) { wm_ = 1.f; wu_ = 0.f; }
     else { wm_ = 0.f; wu_ = 1.f; }
-    const float isd = a.inv_sqrt_d;
+    const float isd = a.inv_sqrt_d * 1.44269504088896f;            // scores in log2 units: exp(x) = exp2(x log2 e)
+    const float clampv = 50.f * 1.44269504088896f;
     static_for<0, 2>([&](auto qt_) __attribute__((always_inline)) {
         constexpr int qt = decltype(qt_)::value;
         const int q = qt * 32 + r31;
+        const half8 qfr = qf[qt];
         // S^T tiles for this query tile: row (key) = (r&3)+8*(r>>2)+4*half (+32 for the 2nd), col (query) = lane&31
         float16v st[2];
-        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qt], zero, 0, 0, 0);
-        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[qt], zero, 0, 0, 0);
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfr, zero, 0, 0, 0);
+        st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qfr, zero, 0, 0, 0);
         const uint64_t mrow = a.mask[q];
-        const float* rb = a.rel_bias ? a.rel_bias + ((size_t)h * 64 + q) * 64 : nullptr;
+        const uint32_t mlo = (uint32_t)mrow, mhi = (uint32_t)(mrow >> 32);
+        const _Float16* rb = a.rel_bias ? &Bs[wave][q][0] : nullptr;
         // scores clamped to [-50,50]: exp needs no max subtraction; masked fill -1e4 underflows to exactly 0
-        float e[2][16];
+        float e[2][16];                          // +exp(score) where the mask allows the key, -exp(score) where not
         float su = 0.f, sm = 0.f;
         static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
             constexpr int kt = decltype(kt_)::value;
+            const uint32_t mw = (kt == 0 ? mlo : mhi) >> (4 * half);       // bit (8 g + j) = key kt*32 + 8 g + 4 half + j
             static_for<0, 4>([&](auto g_) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_)::value;
                 const int key0 = kt * 32 + 8 * g + 4 * half;
-                float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rb) bias = *reinterpret_cast<const float4*>(rb + key0);
-                const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+                half4v bias = {0, 0, 0, 0};
+                if (rb) bias = *reinterpret_cast<const half4v*>(rb + key0);
+                const float bb[4] = {(float)bias[0], (float)bias[1], (float)bias[2], (float)bias[3]};
                 static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
                     constexpr int j = decltype(j_)::value;
                     float d = st[kt][4 * g + j] * isd + bb[j];
-                    d = fminf(fmaxf(d, -50.f), 50.f);
-                    const float eu = __expf(d);
-                    e[kt][4 * g + j] = eu;
+                    d = __builtin_amdgcn_fmed3f(d, -clampv, clampv);
+                    const float eu = __builtin_amdgcn_exp2f(d);
+                    const float es = (mw & (1u << (8 * g + j))) ? eu : -eu;
+                    e[kt][4 * g + j] = es;
                     su += eu;
-                    sm += ((mrow >> (key0 + j)) & 1ull) ? eu : 0.f;
+                    sm += fmaxf(es, 0.f);
                 });
             });
         });
         su += __shfl_xor(su, 32);
         sm += __shfl_xor(sm, 32);
         const float cu = wu_ / su, cm = wm_ / sm;
-        float o[16];
-        static_for<0, 16>([&](auto d_) __attribute__((always_inline)) { o[decltype(d_)::value] = 0.f; });
+        // probabilities (both branches folded into one weight) as the B operand, O^T accumulated over the 4 key blocks
+        float16v oacc = zero;
         static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
             constexpr int kt = decltype(kt_)::value;
-            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
-                constexpr int r = decltype(r_)::value;
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float p = e[kt][r] * (cu + (((mrow >> key) & 1ull) ? cm : 0.f));
-                // keep the V-row loads of different keys from being hoisted together (512 VGPRs + spills otherwise)
-                if ((r & 1) == 0) asm volatile("" ::: "memory");
-                const float4* vr = reinterpret_cast<const float4*>(&Vs[wave][key][0]);
-                const float4 v0 = vr[0], v1 = vr[1], v2 = vr[2], v3 = vr[3];
-                o[0] += p * v0.x; o[1] += p * v0.y; o[2] += p * v0.z; o[3] += p * v0.w;
-                o[4] += p * v1.x; o[5] += p * v1.y; o[6] += p * v1.z; o[7] += p * v1.w;
-                o[8] += p * v2.x; o[9] += p * v2.y; o[10] += p * v2.z; o[11] += p * v2.w;
-                o[12] += p * v3.x; o[13] += p * v3.y; o[14] += p * v3.z; o[15] += p * v3.w;
+            static_for<0, 2>([&](auto jb_) __attribute__((always_inline)) {
+                constexpr int jb = decltype(jb_)::value;
+                half8 pf;
+                static_for<0, 8>([&](auto u_) __attribute__((always_inline)) {
+                    constexpr int u = decltype(u_)::value;
+                    constexpr int r = 8 * jb + u;                          // key = kt*32 + (r&3) + 8*(r>>2) + 4*half
+                    pf[u] = (_Float16)(fabsf(e[kt][r]) * cu + fmaxf(e[kt][r], 0.f) * cm);
+                });
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt][jb], pf, oacc, 0, 0, 0);
             });
         });
-        half8 o0, o1;
-        static_for<0, 8>([&](auto d_) __attribute__((always_inline)) {
-            constexpr int d = decltype(d_)::value;
-            const float x0 = o[d] + __shfl_xor(o[d], 32);
-            const float x1 = o[8 + d] + __shfl_xor(o[8 + d], 32);
-            o0[d] = (_Float16)x0; o1[d] = (_Float16)x1;
-        });
-        if (live) {
-            _Float16* op = a.o + ((size_t)b * 64 + q) * C + h * 16;
-            if (half == 0) *reinterpret_cast<half8*>(op) = o0;
-            else *reinterpret_cast<half8*>(op + 8) = o1;
-        }
+        // O^T: lane = query, regs 0..7 = head dims (r&3) + 8*(r>>2) + 4*half -> 16 contiguous bytes per lane after one
+        // exchange with the other half
+        typedef _Float16 half2v_ __attribute__((ext_vector_type(2)));
+        union { half2v_ h2[2]; uint32_t u[2]; } lo4, hi4, rcv;
+        lo4.h2[0] = half2v_{(_Float16)oacc[0], (_Float16)oacc[1]}; lo4.h2[1] = half2v_{(_Float16)oacc[2], (_Float16)oacc[3]};
+        hi4.h2[0] = half2v_{(_Float16)oacc[4], (_Float16)oacc[5]}; hi4.h2[1] = half2v_{(_Float16)oacc[6], (_Float16)oacc[7]};
+        rcv.u[0] = __shfl_xor(half ? lo4.u[0] : hi4.u[0], 32);
+        rcv.u[1] = __shfl_xor(half ? lo4.u[1] : hi4.u[1], 32);
+        uint4 ov;
+        if (half == 0) ov = make_uint4(lo4.u[0], lo4.u[1], rcv.u[0], rcv.u[1]);    // d 0..3 own, 4..7 from the partner
+        else ov = make_uint4(rcv.u[0], rcv.u[1], hi4.u[0], hi4.u[1]);              // d 8..11 from the partner, 12..15 own
+        *reinterpret_cast<uint4*>(a.o + ((size_t)b * 64 + q) * C + h * 16 + 8 * half) = ov;
     });
+    }
 }
 
 hipError_t launch_attn_core(const AttnArgs& a, hipStream_t st) {
-    long njobs = (long)a.B * a.H;
-    hipLaunchKernelGGL(attn_core_kernel, dim3((unsigned)((njobs + 3) / 4)), dim3(256), 0, st, a);
+    const int hgroups = (a.H + 3) / 4, bgroups = (a.B + ATT_BOARDS - 1) / ATT_BOARDS;
+    hipLaunchKernelGGL(attn_core_kernel, dim3((unsigned)(hgroups * bgroups)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
