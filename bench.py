@@ -209,7 +209,7 @@ def main():
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "time_split_ms_per_step": {"net": ms_net / args.gpus / max(1, args.steps), "tree": ms_tree / args.gpus / max(1, args.steps),
                                        "host": ms_host / args.gpus / max(1, args.steps)},
-            "roofline": {"bound": "mfma", "kernel": "conv_big_kernel<9,*> (3x3 320->320 implicit GEMM, MFMA 32x32x16 f16)",
+            "roofline": {"bound": "mfma", "kernel": "conv_pp_kernel<*> (3x3 320->320 implicit GEMM, MFMA 32x32x16 f16)",
                          "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
                          "launches": int(conv_launches), "avg_launch_us": (conv_ms * 1e3 / conv_launches) if conv_launches else None,
