@@ -9,6 +9,8 @@
 //   waves 0-3: L(y,a) ends at barrier 4y+2a, C(y,a) at 4y+2a+1     y = half-tile, a = k slice within it
 //   waves 4-7: L(y,a) ends at barrier 4y+2a+1, C(y,a) at 4y+2a+2
 //   L = fragment reads of slice (y,a) [+ DMA issue and vmcnt when a == 1],  C = the slice's 10 MFMAs
+// (Past the last half-tile the loop keeps issuing: the last one again, into slots nobody reads, so that every
+//  L(y,1) issues exactly three pieces and the counted wait never changes.)
 // RAW: half-tile y is first read in L(y,0) of waves 0-3, after barrier 4y-1; every wave retires its DMA pieces of y
 //      with vmcnt(6) at the end of L(y-1,1), i.e. before barrier 4y-2 (waves 0-3) / 4y-1 (waves 4-7).
 // WAR: the pieces of half-tile y+3 overwrite the slot of y-1 and are issued in L(y,1), after barrier 4y+1 (4y+2);
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     };
     // the three DMA pieces this wave contributes to half-tile y; `xi`/`c0` = position of the issuing phase
     auto issue_half = [&](int y, int c0, int xi) __attribute__((always_inline)) {
+#ifdef PP_SLIM_DMA
+        {   // timing experiment: the three pieces with no address arithmetic and no branches (wrong data)
+            pp_glds16(w_blk, W_lds + wave * 1024);
+            pp_glds16(w_blk, W_lds + (8 + wave) * 1024);
+            pp_glds16(w_blk, D_lds + (wave & 3) * 1024);
+            return;
+        }
+#endif
         const char* src = w_blk + (size_t)(y >> 1) * w_kt_stride + (size_t)(y & 1) * WH_BYTES;
         char* dst = W_lds + (y & 3) * WH_BYTES;
         pp_glds16(src + wave * 1024, dst + wave * 1024);
@@ -143,28 +153,76 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     if (wn == 1) __builtin_amdgcn_s_setprio(1);
 #endif
 
+    // ---- steady-state DMA: everything that addresses it is wave-uniform (SGPR) and advanced incrementally; the only
+    // per-lane parts are two constant 32-bit offsets (the address arithmetic and branches of the first version of this
+    // loop cost 30% of the kernel: 499 -> 340 us in the stand-alone bench when replaced by fixed addresses) ----
+    const uint32_t w_lane = (uint32_t)lane * 16u;
+    const uint32_t a_lane = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u +
+                            16u * (uint32_t)((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));   // piece q = 4 xi + wave - 4
+    const char* w_base = reinterpret_cast<const char*>(a.w) + (size_t)blockIdx.y * (2 * WH_BYTES) + wave * 1024;  // uniform
+    int t_next = 3;                                      // half-tile the next issue fetches
+    const char* w_ptr = w_base + (size_t)1 * w_kt_stride + WH_BYTES;     // half-tile 3 = K-tile 1, half 1
+    int w_slot = 3 * WH_BYTES;                           // LDS offset of slot t_next & 3
+    const char* a_ptr = in_bytes;                        // group 1: next activation piece of the next chunk
+    int a_dst = 0, a_left = 0;
+    auto issue_next = [&](auto G_) __attribute__((always_inline)) {
+        constexpr int G = decltype(G_)::value;
+        char* dst = W_lds + w_slot + wave * 1024;
+        pp_glds16(w_ptr + w_lane, dst);
+        pp_glds16(w_ptr + 8192 + w_lane, dst + 8192);
+        if constexpr (G == 0) {
+            pp_glds16(w_ptr + 16384 + w_lane, dst + 16384);
+        } else {
+            const bool have = a_left > 0;
+            pp_glds16((have ? a_ptr : in_bytes) + a_lane, have ? A_lds + a_dst : D_lds + (wave - 4) * 1024);
+            a_ptr += have ? (size_t)32 * Cin * 2 : 0;
+            a_dst += have ? 4096 : 0;
+            a_left -= have ? 1 : 0;
+        }
+        // advance to the next half-tile; past the end the last one is fetched again into a slot nobody reads
+        const bool more = t_next + 1 < NH;
+        const size_t inc = (t_next & 1) ? (w_kt_stride - WH_BYTES) : (size_t)WH_BYTES;   // odd -> even: next K-tile
+        w_ptr += more ? inc : 0;
+        t_next += 1;
+        w_slot = (t_next & 3) * WH_BYTES;
+    };
+
     half8 fa0 = {}, fa1 = {}, fb[NT] = {};
-    const char* abase[2];
-    int afx[2];
+    const char* abase[2] = {Z_lds, Z_lds};
+    int afx[2] = {0, 0};
     int y = 0;
 #ifdef PP_TRACE
     const bool trace_on = blockIdx.x == PP_TRACE_BLOCK && (wave & 3) == 0;
     int kt = 0;
 #endif
+    // the loop is instantiated once per ping-pong group: the third DMA piece differs (weights / activations)
+    auto main_loop = [&](auto G_) __attribute__((always_inline)) {
+    constexpr int G = decltype(G_)::value;
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
         const char* Ab = A_lds + (c & 1) * A_BYTES;
+        if constexpr (G == 1) {                          // this wave's 8 pieces of the next chunk's activations
+            a_left = c + 1 < nchunk ? 8 : 0;
+            a_ptr = in_bytes + ((size_t)(m0 + 8 * (wave - 4)) * Cin + (size_t)(c + 1) * 64) * 2;
+            a_dst = ((c + 1) & 1) * A_BYTES + (wave - 4) * 1024;
+        }
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            auto set_tap = [&](int dy, int dx) __attribute__((always_inline)) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int yy = py[mi] + dy, xx = px[mi] + dx;
-                const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
-                const int pp = prow[mi] + dy * 8 + dx;
-                abase[mi] = ok ? Ab + pp * 128 : Z_lds;
-                afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
-            }
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int yy = py[mi] + dy, xx = px[mi] + dx;
+                    const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
+                    const int pp = prow[mi] + dy * 8 + dx;
+                    abase[mi] = ok ? Ab + pp * 128 : Z_lds;
+                    afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
+                }
+            };
+#ifdef PP_SLIM_TAP
+            if (c == 0 && tap == 0) set_tap(0, 0);          // timing experiment: no per-tap address work (wrong data)
+#else
+            set_tap(tap / 3 - 1, tap - (tap / 3) * 3 - 1);
+#endif
             static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_)::value;      // 16-deep k slice of the K-tile
                 constexpr int h = j >> 1;
@@ -184,15 +242,19 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                 asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]) : "v"(Wb), "v"(abase[0]), "v"(abase[1]));
 #endif
                 if constexpr ((j & 1) == 1) {
-                    if (yh + 3 < NH) {
 #ifndef PP_NO_DMA
-                        issue_half(yh + 3, c, tap * 2 + h);
-                        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    issue_next(G_);
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #endif
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
                 }
+#ifdef PP_DUMMY_VALU
+                {   // timing experiment: extra VALU work in the load section
+                    int dv = lane;
+#pragma unroll
+                    for (int u = 0; u < PP_DUMMY_VALU; ++u) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dv));
+                    asm volatile("" :: "v"(dv));
+                }
+#endif
                 PP_LSETPRIO(0);
                 PP_STAMP(1);
                 PP_FENCE();
@@ -220,6 +282,10 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
 #endif
         }
     }
+    };
+    if (wn == 0) main_loop(std::integral_constant<int, 0>{});
+    else main_loop(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's refetches land before the epilogue reuses LDS
     if (wn == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
 
 #ifdef PP_NO_EPILOGUE

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
         gatev[0] = g0.x; gatev[1] = g0.y; gatev[2] = g0.z; gatev[3] = g0.w;
         gatev[4] = g1.x; gatev[5] = g1.y; gatev[6] = g1.z; gatev[7] = g1.w;
     }
+    // (the second output's GroupNorm parameters too: a late load is one more exposed latency per board)
+    float g2w = 0.f, g2b = 0.f;
+    if (a.y2 != nullptr && tid < C) { g2w = a.gn2_gamma[tid]; g2b = a.gn2_beta[tid]; }
     half8 tv[4], rv[4];
     static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
         constexpr int k = decltype(k_)::value;
@@ -414,16 +417,16 @@ __global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
     if (a.y2 == nullptr) return;
     __syncthreads();
     // 5. second output from the register copy of y
-    for (int c = tid; c < C; c += nthr) {
-        const int g0 = (c >> 4) << 4;
+    if (tid < C) {                                       // nthr == 2 C
+        const int c = tid, g0 = (c >> 4) << 4;
         float s = 0.f, ss = 0.f;
         for (int j = 0; j < 16; ++j) { s += tot[2 * (g0 + j)]; ss += tot[2 * (g0 + j) + 1]; }
         const float mean = s * (1.f / 1024.f);
         float var = ss * (1.f / 1024.f) - mean * mean;
         var = var > 0.f ? var : 0.f;
-        const float g = a.gn2_gamma[c] * rsqrtf(var + 1e-5f);
+        const float g = g2w * rsqrtf(var + 1e-5f);
         sc[c] = g;
-        sh[c] = a.gn2_beta[c] - mean * g;
+        sh[c] = g2b - mean * g;
     }
     __syncthreads();
     _Float16* y2 = a.y2 + (size_t)b * 64 * C + (size_t)(sg * 4) * C + c0;
