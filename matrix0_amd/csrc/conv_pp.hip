@@ -17,6 +17,7 @@
 //      the last reads of y-1 (waves 4-7, L(y-1,1)) are retired by the lgkmcnt wait of C(y-1,1), before barrier 4y.
 #include "kernel_common.h"
 #include "conv_epilogue.h"
+#include "conv_tail.h"
 
 __device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_wave_base) {
     // LDS destination = wave-uniform base + lane*16 (hardware); the global source is per lane
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     asm volatile("" :: "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]), "v"(acc[1][4]));
 #else
     // every wave is past its last LDS read and DMA wait here (the barrier just above / the loop's final one)
-    conv_tile_epilogue<EPI, ACT, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
+    if constexpr (EPI == 3) conv_tail_epilogue<ACT>(acc, a, smem, m0, wm, wn, wave, lane);
+    else conv_tile_epilogue<EPI, ACT, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
 #endif
 }
 
@@ -317,6 +319,14 @@ hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st) {
     if (a.Cin % 64 != 0 || a.Npad % 320 != 0 || a.Mrows % 256 != 0) return hipErrorInvalidValue;
     if (a.mul != nullptr || a.out_f32 != 0) return hipErrorInvalidValue;      // 3x3 convs never use these
     if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
+    if (a.res != nullptr) {                     // conv2 of a block with the block's tail fused (conv_tail.h)
+        if (a.N != 320 || a.Npad != 320 || a.ldo != 320 || a.bias != nullptr || a.out_stats != nullptr) return hipErrorInvalidValue;
+        if (a.y2 != nullptr && a.gn_gamma == nullptr) return hipErrorInvalidValue;
+        if (a.se_w1 != nullptr && (a.se_hidden < 4 || a.se_hidden > 128 || a.se_hidden % 4 != 0)) return hipErrorInvalidValue;
+        if (a.epi_act == ACT_SILU) return launch_conv_pp_e<3, ACT_SILU>(a, st);
+        if (a.epi_act == ACT_RELU) return launch_conv_pp_e<3, ACT_RELU>(a, st);
+        return hipErrorInvalidValue;
+    }
     if (a.gn_gamma != nullptr) {                // conv1 of a block: GroupNorm + the network activation
         if (a.epi_act == ACT_SILU) return launch_conv_pp_e<1, ACT_SILU>(a, st);
         if (a.epi_act == ACT_RELU) return launch_conv_pp_e<1, ACT_RELU>(a, st);

@@ -1,0 +1,216 @@
+// Residual-block tail fused into conv2's epilogue (conv_pp_kernel, EPI 3):
+//   t      = conv2 output (this workgroup holds 4 whole boards x all 320 channels in its accumulators)
+//   gate   = sigmoid(W2 act(W1 mean_squares(t) + b1) + b2)            squeeze-excite, resnet.py:59-68 (optional)
+//   y      = x + gate * t                                             the residual stream          -> a.out
+//   y2     = act(GroupNorm16(y; next block's bn1))                    the next conv1's operand     -> a.y2 (optional)
+// i.e. what conv2's plain epilogue + se_gate_kernel + ew_board_kernel did with three launches and two more trips of
+// the tensor through HBM.  Everything a board needs is inside the workgroup, so the only new global traffic is the
+// read of x.  The phases, all 8 waves together (LDS is free once the main loop is over):
+//   A  per-board channel means of t from the accumulators                         -> LDS pool[4][C]
+//   B  W1 (C x Hd f32) by global_load_lds -> LDS, hidden = act(W1 pool + b1);  W2 likewise, gate -> LDS; each lane
+//      picks up the 5 gate values of its accumulator columns
+//   C  gate * t staged as fp16 in the wave's private LDS image [64 rows][160 ch]   (conv_stage_tile)
+//   D  lane = (16-byte channel chunk, row mod 3): add x (global, 16-byte loads issued up front), store y, write y back
+//      to the image, per-channel sums -> GroupNorm statistics of the wave's 10 groups by shuffles
+//   E  second pass over the image: y2 = act(y * scale + shift), 16-byte stores
+// Phases C-E touch only the wave's own image: no workgroup barrier after B.
+#pragma once
+#include "conv_epilogue.h"
+
+__device__ __forceinline__ void tail_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// C == 320 (one N block), 8 waves: wave = (board wm, channel half wn), NT == 5.
+template <int ACT>
+__device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const GemmArgs& a, char* smem, int m0, int wm,
+                                                   int wn, int wave, int lane) {
+    constexpr int NT = 5, C = 320;
+    const int tid = wave * 64 + lane;
+    const int r31 = lane & 31, half = lane >> 5;
+    float* pool = reinterpret_cast<float*>(smem);              // [C][4 boards]   5120 B (one 16-byte read per channel)
+    float* gate = pool + 4 * C;                                // [4][C]          5120 B
+    float* hid = gate + 4 * C;                                 // [Hd<=128][4]    2048 B
+    float* part = hid + 4 * 128;                               // [parts<=8][4][Hd<=128] 16384 B
+    float* wst = reinterpret_cast<float*>(smem + 32768);       // staged W1 / W2: C*Hd*4 <= 131072 B - 32768
+    const int Hd = a.se_hidden;
+    const bool se = a.se_w1 != nullptr;
+    float gv[NT];
+    if (se) {
+        const int wbytes = C * Hd * 4;                          // multiple of 1024 (C = 320)
+        const int npieces = wbytes >> 10;
+        // B1 (issued first, lands while phase A runs): W1 -> LDS
+        for (int p = wave; p < npieces; p += 8)
+            tail_glds16(reinterpret_cast<const char*>(a.se_w1) + p * 1024 + lane * 16, reinterpret_cast<char*>(wst) + p * 1024);
+        // A: channel means of this wave's board / channel half
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            float s = 0.f;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { s += acc[decltype(mi_)::value][ni][decltype(r_)::value]; });
+            });
+            s += __shfl_xor(s, 32);
+            if (lane < 32) pool[(wn * 160 + ni * 32 + r31) * 4 + wm] = s * (1.f / 64.f);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // B2: hidden = act(W1 pool + b1); thread = (hidden unit j, channel part), the 4 boards at once; w1 is [C][Hd]
+        const int parts = 512 / Hd > 8 ? 8 : 512 / Hd;
+        {
+            const int j = tid % Hd, p = tid / Hd;
+            if (p < parts) {
+                const int cpp = (C + parts - 1) / parts;
+                const int cbeg = p * cpp, cend = cbeg + cpp < C ? cbeg + cpp : C;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 6
+                for (int c = cbeg; c < cend; ++c) {
+                    const float w = wst[c * Hd + j];
+                    const float4 pv = *reinterpret_cast<const float4*>(pool + c * 4);
+                    s0 += w * pv.x; s1 += w * pv.y; s2 += w * pv.z; s3 += w * pv.w;
+                }
+                float* pp = part + (p * 4) * 128 + j;
+                pp[0] = s0; pp[128] = s1; pp[256] = s2; pp[384] = s3;
+            }
+        }
+        __syncthreads();
+        // B3: W2 -> LDS (W1 is dead), meanwhile the hidden units
+        for (int p = wave; p < npieces; p += 8)
+            tail_glds16(reinterpret_cast<const char*>(a.se_w2) + p * 1024 + lane * 16, reinterpret_cast<char*>(wst) + p * 1024);
+        for (int i = tid; i < 4 * Hd; i += 512) {
+            const int b = i / Hd, j = i - b * Hd;
+            float s = a.se_b1[j];
+            for (int p = 0; p < parts; ++p) s += part[(p * 4 + b) * 128 + j];
+            hid[j * 4 + b] = act_fast<ACT>(s);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // B4: gate = sigmoid(W2 hidden + b2); thread = channel (first 320 threads), the 4 boards at once; w2 is [Hd][C]
+        if (tid < C) {
+            const float b2 = a.se_b2[tid];
+            float s0 = b2, s1 = b2, s2 = b2, s3 = b2;
+#pragma unroll 8
+            for (int j = 0; j < Hd; ++j) {
+                const float w = wst[j * C + tid];
+                const float4 hv = *reinterpret_cast<const float4*>(hid + j * 4);
+                s0 += w * hv.x; s1 += w * hv.y; s2 += w * hv.z; s3 += w * hv.w;
+            }
+            gate[tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s0));
+            gate[C + tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s1));
+            gate[2 * C + tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s2));
+            gate[3 * C + tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s3));
+        }
+        __syncthreads();
+        // B5: the gate values of this lane's accumulator columns
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            gv[ni] = gate[wm * C + wn * 160 + ni * 32 + r31];
+        });
+        __syncthreads();                                          // the images below overwrite pool / gate / wst
+    } else {
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) { gv[decltype(ni_)::value] = 1.f; });
+    }
+
+    // C: gate * t -> the wave's fp16 image
+    char* img = smem + wave * (NT * 64 * 64);
+    char* wbase = conv_stage_base<NT>(img, lane);
+    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+        constexpr int ni = decltype(ni_)::value;
+        static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+            constexpr int mi = decltype(mi_)::value;
+            float v[16];
+            static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_)::value;
+                v[r] = acc[mi][ni][r] * gv[ni];
+            });
+            conv_stage_tile<NT, mi, ni>(v, wbase, lane);
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // D: y = x + image; lane = (chunk of 8 channels, row mod 3), rows rsub, rsub+3, ...; lanes 60..63 idle
+    constexpr int NCH = NT * 4;                                  // 20 chunks per 160-channel row
+    constexpr int NIT = 22;                                      // ceil(64 / 3)
+    const int chunk = lane % NCH, rsub = lane / NCH;
+    const bool lane_on = rsub < 3;
+    const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
+    const size_t tile_off = ((size_t)(m0 + wm * 64) * a.ldo + wn * 160) * 2;      // wave-uniform
+    const char* xin = reinterpret_cast<const char*>(a.res) + tile_off;
+    char* yout = reinterpret_cast<char*>(a.out) + tile_off;
+    const int rows_valid = a.Mvalid - (m0 + wm * 64);
+    const uint32_t lane_goff = (uint32_t)rsub * ldo2 + (uint32_t)chunk * 16u;
+    const uint32_t lane_loff = (uint32_t)(rsub * NCH + chunk) * 16u;
+    half8 xv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = rsub + 3 * it;
+        xv[it] = (lane_on && row < 64) ? *reinterpret_cast<const half8*>(xin + (lane_goff + (uint32_t)(3 * it) * ldo2))
+                                       : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float csum[8], csq[8];
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = rsub + 3 * it;
+        if (lane_on && row < 64) {
+            half8* ip = reinterpret_cast<half8*>(img + lane_loff + (uint32_t)(3 * it * NCH) * 16u);
+            const half8 tv = *ip;
+            half8 yv;
+            static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value;
+                const float y = (float)tv[i] + (float)xv[it][i];
+                yv[i] = (_Float16)y;
+                csum[i] += y; csq[i] += y * y;
+            });
+            *ip = yv;
+            if (row < rows_valid) *reinterpret_cast<half8*>(yout + (lane_goff + (uint32_t)(3 * it) * ldo2)) = yv;
+        }
+    }
+    if (a.y2 == nullptr) return;
+
+    // GroupNorm statistics of y: over the 3 row classes (lanes chunk, chunk+20, chunk+40), then over the group's 16
+    // channels = this lane's 8 + the neighbour chunk's 8
+    float gs = 0.f, gss = 0.f;
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { gs += csum[decltype(i_)::value]; gss += csq[decltype(i_)::value]; });
+    {
+        const float s1 = __shfl(gs, chunk + NCH), s2 = __shfl(gs, chunk + 2 * NCH);
+        const float q1 = __shfl(gss, chunk + NCH), q2 = __shfl(gss, chunk + 2 * NCH);
+        gs = __shfl(gs, chunk) + s1 + s2;                        // every lane: totals of its chunk (same order everywhere)
+        gss = __shfl(gss, chunk) + q1 + q2;
+        const float so = __shfl_xor(gs, 1), qo = __shfl_xor(gss, 1);      // partner chunk (chunk ^ 1 is lane ^ 1 for lanes < 60)
+        const float lo_s = (chunk & 1) ? so : gs, hi_s = (chunk & 1) ? gs : so;
+        const float lo_q = (chunk & 1) ? qo : gss, hi_q = (chunk & 1) ? gss : qo;
+        gs = lo_s + hi_s; gss = lo_q + hi_q;
+    }
+    const float mean = gs * (1.f / 1024.f);
+    float var = gss * (1.f / 1024.f) - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + 1e-5f);
+    float scl[8], shl[8];
+    {
+        const int c0 = wn * 160 + chunk * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gn_gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gn_gamma + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.gn_beta + c0), b1 = *reinterpret_cast<const float4*>(a.gn_beta + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value;
+            scl[i] = gg[i] * rstd; shl[i] = bb[i] - mean * scl[i];
+        });
+    }
+    // E: y2 = act(GroupNorm(y)) from the image
+    char* y2out = reinterpret_cast<char*>(a.y2) + tile_off;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = rsub + 3 * it;
+        if (lane_on && row < 64 && row < rows_valid) {
+            const half8 yv = *reinterpret_cast<const half8*>(img + lane_loff + (uint32_t)(3 * it * NCH) * 16u);
+            half8 ov;
+            static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value;
+                ov[i] = (_Float16)act_fast<ACT>((float)yv[i] * scl[i] + shl[i]);
+            });
+            *reinterpret_cast<half8*>(y2out + (lane_goff + (uint32_t)(3 * it) * ldo2)) = ov;
+        }
+    }
+}

@@ -76,6 +76,8 @@ public:
     // Dominant-kernel timing (roofline): when enabled every 3x3 C->C conv launch is bracketed by HIP events on
     // the launch stream; harvest after the stream has been synchronised.
     void set_profile(bool on) { profile_ = on; }
+    hipError_t run_conv_tail(const ResBlockW& r, const _Float16* in, const _Float16* x, _Float16* y,
+                             const NormParams* next_bn1, _Float16* y2, int act, int Mrows, hipStream_t st);
     void harvest_profile();
     double prof_conv_ms() const { return prof_ms_; }
     double prof_conv_flop() const { return prof_flop_; }

@@ -371,6 +371,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
                          const NormParams* out_norm, int epi_act, const _Float16* mul, float* out_stats,
                          bool out_f32, float out_scale, hipStream_t st) {
     GemmArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = in; a.w = g.w; a.out = out;
     a.gn_gamma = out_norm ? out_norm->gamma : nullptr;
     a.gn_beta = out_norm ? out_norm->beta : nullptr;
@@ -389,6 +390,33 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
         (void)hipEventRecord(pev_[pev_used_ + 1], st);
         pev_used_ += 2;
         pflop_.push_back(2.0 * (double)Mvalid * (double)g.N * (double)g.Cin * 9.0);
+    }
+    return rc;
+}
+
+hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Float16* x, _Float16* y,
+                              const NormParams* next_bn1, _Float16* y2, int act, int Mrows, hipStream_t st) {
+    const PackedGemm& g = r.conv2;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.w = g.w; a.out = y;
+    a.Mrows = Mrows; a.Mvalid = Mrows; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
+    a.epi_act = act; a.out_scale = 1.f; a.w_pp = g.pp ? 1 : 0;
+    a.res = x;
+    if (next_bn1 && y2) { a.y2 = y2; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }
+    if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden; }
+    const bool timed = profile_;
+    if (timed) {
+        if (pev_used_ + 2 > pev_.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return hipErrorOutOfMemory; pev_.push_back(e); }
+        }
+        (void)hipEventRecord(pev_[pev_used_], st);
+    }
+    hipError_t rc = launch_conv_gemm(a, 9, st);
+    if (timed) {
+        (void)hipEventRecord(pev_[pev_used_ + 1], st);
+        pev_used_ += 2;
+        pflop_.push_back(2.0 * (double)Mrows * (double)g.N * (double)g.Cin * 9.0);
     }
     return rc;
 }
@@ -487,6 +515,9 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, nullptr, nullptr, xa, nullptr, first_bn1, AA_, C, Bp));
     }
     // tower
+    const char* ftenv = getenv("M0_FUSE_TAIL");          // =0: conv2 + se_gate + ew_board as separate kernels
+    const bool fuse_tail = big && C == 320 && !(ftenv && ftenv[0] == '0') &&
+                           (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
     for (size_t li = 0; li < tower_.size(); ++li) {
         const TowerLayer& L = tower_[li];
         if (L.kind == 0) {
@@ -499,8 +530,13 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
                 KCHK(run_gemm(r.conv1, AA_, T2_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
                 KCHK(ew(T2_, S1_, &r.bn2, nullptr, nullptr, nullptr, nullptr, T1_, nullptr, nullptr, nullptr, C, Bp));
             }
-            KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, nullptr, 0, nullptr, S2_, false, 1.f, st));
-            KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
+            if (fuse_tail) {
+                // conv2 + squeeze-excite + residual add + the next block's GroupNorm/activation in one kernel
+                KCHK(run_conv_tail(r, T1_, xa, xb, next_bn1_after(li), AA_, act, Mc, st));
+            } else {
+                KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, nullptr, 0, nullptr, S2_, false, 1.f, st));
+                KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
+            }
             std::swap(xa, xb);
         } else {
             if (L.skip) continue;

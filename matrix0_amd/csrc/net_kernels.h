@@ -24,6 +24,15 @@ struct GemmArgs {
     int out_f32;
     float out_scale;
     int w_pp;                // 3x3 big tile: w is in conv_pp_kernel's half-tile layout (pack_gemm)
+    // residual-block tail fused into the epilogue (conv_tail.h), when res != null: out = res + gate * conv,
+    // y2 = epi_act(GroupNorm16(out; gn_gamma, gn_beta)) when y2 != null, gate from se_* when se_w1 != null
+    const _Float16* res;     // [Mrows][ldo]
+    _Float16* y2;            // [Mrows][ldo] or null
+    const float* se_w1;      // [C][Hd] (transposed)
+    const float* se_b1;
+    const float* se_w2;      // [Hd][C] (transposed)
+    const float* se_b2;
+    int se_hidden;
 };
 
 struct EwArgs {

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""A/B the fused residual-block tail (conv_tail.h) against conv2 + se_gate + ew_board in one process.
+
+M0_FUSE_TAIL is read at every forward, so one network serves both paths: output difference on random positions,
+then interleaved timing rounds at B boards."""
+import sys, os, json
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import net_ref
+from matrix0_amd.backend import M0Backend
+
+cfg = dict(planes=19, channels=320, blocks=24, attention_heads=20, policy_size=4672, norm="group",
+           activation="silu", preact=True, policy_factor_rank=128, self_supervised=True,
+           ssl_tasks=["piece", "threat", "pin", "fork", "control"])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+sd = net_ref.random_state_dict(cfg, seed=0)
+net = M0Backend.from_state_dict(cfg, sd)
+rng = np.random.default_rng(1)
+x = (rng.random((70, 19, 8, 8)) < 0.1).astype(np.float32)
+outs = {}
+for name, env in (("split", "0"), ("fused", "1")):
+    os.environ["M0_FUSE_TAIL"] = env
+    outs[name] = net.infer_np(x)
+dp = float(np.abs(outs["split"][0] - outs["fused"][0]).max())
+dv = float(np.abs(outs["split"][1] - outs["fused"][1]).max())
+print(json.dumps({"max_dlogit_split_vs_fused": dp, "max_dvalue": dv,
+                  "logit_scale": float(np.abs(outs["split"][0]).max())}), flush=True)
+for r in range(rounds):
+    for name, env in (("split", "0"), ("fused", "1")):
+        os.environ["M0_FUSE_TAIL"] = env
+        ms = net.bench_forward(B, 3)
+        print(json.dumps({"round": r, "path": name, "B": B, "fwd_ms": round(ms, 3)}), flush=True)
