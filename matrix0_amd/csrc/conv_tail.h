@@ -36,8 +36,26 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
     float* wst = reinterpret_cast<float*>(smem + 32768);       // staged W1 / W2: C*Hd*4 <= 131072 B - 32768
     const int Hd = a.se_hidden;
     const bool se = a.se_w1 != nullptr;
+    // phase D/E lane mapping and the second output's GroupNorm parameters (fetched now: a late load is an exposed
+    // global-memory latency in a kernel with one workgroup per CU)
+    constexpr int NCH = NT * 4;                                  // 20 chunks per 160-channel row
+    constexpr int NIT = 22;                                      // ceil(64 / 3)
+    const int chunk = lane % NCH, rsub = lane / NCH;
+    const bool lane_on = rsub < 3;
+    float gg[8], bb[8];
+    if (a.y2 != nullptr) {
+        const int c0 = wn * 160 + chunk * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gn_gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gn_gamma + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.gn_beta + c0), b1 = *reinterpret_cast<const float4*>(a.gn_beta + c0 + 4);
+        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
     float gv[NT];
+#ifdef TAIL_NO_SE
+    if (false) {
+#else
     if (se) {
+#endif
         const int wbytes = C * Hd * 4;                          // multiple of 1024 (C = 320)
         const int npieces = wbytes >> 10;
         // B1 (issued first, lands while phase A runs): W1 -> LDS
@@ -111,9 +129,18 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
         static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) { gv[decltype(ni_)::value] = 1.f; });
     }
 
-    // C: gate * t -> the wave's fp16 image
+    // C: gate * t -> the wave's fp16 image; the loads of x are issued between the tile columns, into the registers
+    // the staged accumulators free (x is 2-3 us away and nothing else runs on this CU)
     char* img = smem + wave * (NT * 64 * 64);
     char* wbase = conv_stage_base<NT>(img, lane);
+    const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
+    const size_t tile_off = ((size_t)(m0 + wm * 64) * a.ldo + wn * 160) * 2;      // wave-uniform
+    const char* xin = reinterpret_cast<const char*>(a.res) + tile_off;
+    char* yout = reinterpret_cast<char*>(a.out) + tile_off;
+    const int rows_valid = a.Mvalid - (m0 + wm * 64);
+    const uint32_t lane_goff = (uint32_t)rsub * ldo2 + (uint32_t)chunk * 16u;
+    const uint32_t lane_loff = (uint32_t)(rsub * NCH + chunk) * 16u;
+    half8 xv[NIT];
     static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
         constexpr int ni = decltype(ni_)::value;
         static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
@@ -125,53 +152,50 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
             });
             conv_stage_tile<NT, mi, ni>(v, wbase, lane);
         });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<ni * 5, (ni * 5 + 5 < NIT ? ni * 5 + 5 : NIT)>([&](auto it_) __attribute__((always_inline)) {
+            constexpr int it = decltype(it_)::value;
+            const int row = rsub + 3 * it;
+#ifdef TAIL_NO_XLOAD
+            xv[it] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#else
+            xv[it] = (lane_on && row < 64) ? *reinterpret_cast<const half8*>(xin + (lane_goff + (uint32_t)(3 * it) * ldo2))
+                                           : half8{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        });
+        __builtin_amdgcn_sched_barrier(0);
     });
-    __builtin_amdgcn_sched_barrier(0);
 
     // D: y = x + image; lane = (chunk of 8 channels, row mod 3), rows rsub, rsub+3, ...; lanes 60..63 idle
-    constexpr int NCH = NT * 4;                                  // 20 chunks per 160-channel row
-    constexpr int NIT = 22;                                      // ceil(64 / 3)
-    const int chunk = lane % NCH, rsub = lane / NCH;
-    const bool lane_on = rsub < 3;
-    const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
-    const size_t tile_off = ((size_t)(m0 + wm * 64) * a.ldo + wn * 160) * 2;      // wave-uniform
-    const char* xin = reinterpret_cast<const char*>(a.res) + tile_off;
-    char* yout = reinterpret_cast<char*>(a.out) + tile_off;
-    const int rows_valid = a.Mvalid - (m0 + wm * 64);
-    const uint32_t lane_goff = (uint32_t)rsub * ldo2 + (uint32_t)chunk * 16u;
-    const uint32_t lane_loff = (uint32_t)(rsub * NCH + chunk) * 16u;
-    half8 xv[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int row = rsub + 3 * it;
-        xv[it] = (lane_on && row < 64) ? *reinterpret_cast<const half8*>(xin + (lane_goff + (uint32_t)(3 * it) * ldo2))
-                                       : half8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    float csum[8], csq[8];
-    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { csum[decltype(i_)::value] = 0.f; csq[decltype(i_)::value] = 0.f; });
+    // The sum of two fp16 numbers rounded to fp16 is what the fp32 add + conversion gives, so y is computed with packed
+    // fp16 adds (4 instructions per 8 channels); the GroupNorm sums (this lane's 8 channels x its rows) use the
+    // 2-element fp16 dot product with fp32 accumulation, on the rounded y (the tensor that is actually stored).
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 ones = {(_Float16)1.f, (_Float16)1.f};
+    float gs = 0.f, gss = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int row = rsub + 3 * it;
         if (lane_on && row < 64) {
             half8* ip = reinterpret_cast<half8*>(img + lane_loff + (uint32_t)(3 * it * NCH) * 16u);
-            const half8 tv = *ip;
-            half8 yv;
-            static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+            const half8 yv = *ip + xv[it];
+            static_for<0, 4>([&](auto i_) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_)::value;
-                const float y = (float)tv[i] + (float)xv[it][i];
-                yv[i] = (_Float16)y;
-                csum[i] += y; csq[i] += y * y;
+                const h2 p = {yv[2 * i], yv[2 * i + 1]};
+                gs = __builtin_amdgcn_fdot2(p, ones, gs, false);
+                gss = __builtin_amdgcn_fdot2(p, p, gss, false);
             });
             *ip = yv;
             if (row < rows_valid) *reinterpret_cast<half8*>(yout + (lane_goff + (uint32_t)(3 * it) * ldo2)) = yv;
         }
     }
+#ifdef TAIL_NO_Y2
+    return;
+#endif
     if (a.y2 == nullptr) return;
 
     // GroupNorm statistics of y: over the 3 row classes (lanes chunk, chunk+20, chunk+40), then over the group's 16
     // channels = this lane's 8 + the neighbour chunk's 8
-    float gs = 0.f, gss = 0.f;
-    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) { gs += csum[decltype(i_)::value]; gss += csq[decltype(i_)::value]; });
     {
         const float s1 = __shfl(gs, chunk + NCH), s2 = __shfl(gs, chunk + 2 * NCH);
         const float q1 = __shfl(gss, chunk + NCH), q2 = __shfl(gss, chunk + 2 * NCH);
@@ -187,17 +211,10 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
     var = var > 0.f ? var : 0.f;
     const float rstd = rsqrtf(var + 1e-5f);
     float scl[8], shl[8];
-    {
-        const int c0 = wn * 160 + chunk * 8;
-        const float4 g0 = *reinterpret_cast<const float4*>(a.gn_gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gn_gamma + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(a.gn_beta + c0), b1 = *reinterpret_cast<const float4*>(a.gn_beta + c0 + 4);
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_)::value;
-            scl[i] = gg[i] * rstd; shl[i] = bb[i] - mean * scl[i];
-        });
-    }
+    static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_)::value;
+        scl[i] = gg[i] * rstd; shl[i] = bb[i] - mean * scl[i];
+    });
     // E: y2 = act(GroupNorm(y)) from the image
     char* y2out = reinterpret_cast<char*>(a.y2) + tile_off;
 #pragma unroll

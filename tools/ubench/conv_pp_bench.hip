@@ -24,6 +24,23 @@ int main(int argc, char** argv) {
     GemmArgs a{};
     a.in = din; a.w = dw; a.out = dout; a.out_stats = dstats; a.Mrows = M; a.Mvalid = M; a.Cin = C; a.N = C; a.Npad = C;
     a.ldo = C; a.out_scale = 1.f; a.w_pp = 1;
+#ifdef BENCH_TAIL   // conv2 with the residual-block tail fused (EPI 3): x, squeeze-excite weights, next GroupNorm, y2
+    {
+        const int Hd = 80;
+        std::vector<float> w1((size_t)C * Hd), w2((size_t)Hd * C), b1(Hd, 0.01f), b2(C, 0.02f), gam(C, 1.f), bet(C, 0.f);
+        for (auto& v : w1) v = rnd() * 0.1f;
+        for (auto& v : w2) v = rnd() * 0.1f;
+        float *dw1, *dw2, *db1, *db2, *dg, *dbt; _Float16 *dres, *dy2;
+        hipMalloc(&dw1, w1.size() * 4); hipMalloc(&dw2, w2.size() * 4); hipMalloc(&db1, Hd * 4); hipMalloc(&db2, C * 4);
+        hipMalloc(&dg, C * 4); hipMalloc(&dbt, C * 4); hipMalloc(&dres, (size_t)M * C * 2); hipMalloc(&dy2, (size_t)M * C * 2);
+        hipMemcpy(dw1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(db1, b1.data(), Hd * 4, hipMemcpyHostToDevice); hipMemcpy(db2, b2.data(), C * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dg, gam.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(dbt, bet.data(), C * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dres, din, (size_t)M * C * 2, hipMemcpyDeviceToDevice);
+        a.out_stats = nullptr; a.res = dres; a.y2 = dy2; a.gn_gamma = dg; a.gn_beta = dbt; a.epi_act = ACT_SILU;
+        a.se_w1 = dw1; a.se_b1 = db1; a.se_w2 = dw2; a.se_b2 = db2; a.se_hidden = Hd;
+    }
+#endif
 #ifdef PP_TRACE
     unsigned long long* dtr; hipMalloc(&dtr, 2 * 4 * 4 * 4 * 8); hipMemset(dtr, 0, 2 * 4 * 4 * 4 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &dtr, sizeof(dtr));
