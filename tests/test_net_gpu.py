@@ -81,6 +81,33 @@ def test_r24_320_vs_oracle():
     assert np.array_equal(p1[0], p[0]) and v1[0] == v[0]
 
 
+def test_fused_block_tail_matches_split_kernels(monkeypatch):
+    """conv2 with the residual-block tail in its epilogue (conv_tail.h) vs conv2 + se_gate + ew_board as three
+    kernels: the same arithmetic with one fp16 rounding moved, on a ragged batch (70 boards = 17.5 tiles), and both
+    against the fp32 oracle.  Also covers a network without squeeze-excite (gate == 1) and relu."""
+    from matrix0_amd.backend import M0Backend
+    for extra in ({}, {"se": False, "activation": "relu"}):
+        cfg = dict(_r24_cfg(), blocks=4, **extra)
+        sd = net_ref.random_state_dict(cfg, seed=3)
+        be = M0Backend.from_state_dict(cfg, sd)
+        g = torch.Generator().manual_seed(11)
+        B = 70
+        x = torch.zeros(B, 19, 8, 8)
+        x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+        x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+        x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+        monkeypatch.setenv("M0_FUSE_TAIL", "0")
+        p_split, v_split = be.infer_np(x.numpy())
+        monkeypatch.setenv("M0_FUSE_TAIL", "1")
+        p_fused, v_fused = be.infer_np(x.numpy())
+        assert np.abs(p_fused - p_split).max() <= 5e-3
+        assert np.abs(v_fused - v_split).max() <= 5e-3
+        p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
+        for p, v in ((p_split, v_split), (p_fused, v_fused)):
+            assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
+            assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
+
+
 def test_infer_np_rejects_bad_shape_and_nan():
     from matrix0_amd.backend import M0Backend
     cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
