@@ -36,8 +36,21 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3;              // board within the tile
     const int wn = wave >> 2;             // N part (32*NT channels = 2*NT whole GroupNorm groups)
-    const int m0 = blockIdx.x * 256;
-    const int n0 = blockIdx.y * 320;
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the N blocks of one
+    // row block are given ids that are consecutive ON ONE XCD -- they run back to back there and the row block's
+    // activations are fetched from HBM once instead of once per N block (qkv: N = 960 = 3 blocks).
+    const int nblk = a.Npad / 320, rblk = a.Mrows >> 8;
+    int rb, nb;
+    if ((rblk & 7) == 0) {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        rb = (q / nblk) * 8 + xcd;
+        nb = q % nblk;
+    } else {
+        rb = blockIdx.x % rblk;
+        nb = blockIdx.x / rblk;
+    }
+    const int m0 = rb * 256;
+    const int n0 = nb * 320;
     const int Cin = a.Cin;
     const int nchunk = Cin >> 6;
     const int nsteps = nchunk * TAPS;
@@ -199,7 +212,7 @@ static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(a.Mrows / 256, a.Npad / 320);
+    dim3 grid((a.Mrows / 256) * (a.Npad / 320));
     hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW>), grid, dim3(256 * WNW), lds, st, a);
     return hipGetLastError();
 }
