@@ -44,19 +44,23 @@ __device__ __forceinline__ void conv_stage_tile(const float (&v)[16], char* wbas
 
 // after all tiles are staged: LDS operations of one wave execute in order, so the reads see the writes.
 // Addresses: uniform 64-bit base + 32-bit lane offset (the launchers reject outputs of 4 GiB or more).
-template <int NT>
+// FENCE_EVERY > 0: at most that many 16-byte pieces in flight (callers that still hold live accumulators)
+template <int NT, int FENCE_EVERY = 0>
 __device__ __forceinline__ void conv_stage_flush(const GemmArgs& a, const char* lds_wave, int m0, int n0, int wm, int wn,
                                                  int lane) {
     constexpr int NCH = NT * 4;                    // 16-byte pieces per staged row
     const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
     char* out = reinterpret_cast<char*>(a.out) + ((size_t)(m0 + wm * 64) * a.ldo + n0 + wn * NT * 32) * 2;   // uniform
     const int rows_valid = a.Mvalid - (m0 + wm * 64);
+    // image unit i = it*64 + lane = row*NCH + ch, advanced incrementally (64 = (64/NCH)*NCH + 64%NCH)
+    int row = lane / NCH, ch = lane - row * NCH;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-        const int i = it * 64 + lane;
-        const int row = i / NCH, ch = i - row * NCH;
-        const uint4 v = *reinterpret_cast<const uint4*>(lds_wave + i * 16);
+        if (FENCE_EVERY > 0 && it % (FENCE_EVERY > 0 ? FENCE_EVERY : 1) == 0) asm volatile("" ::: "memory");
+        const uint4 v = *reinterpret_cast<const uint4*>(lds_wave + (it * 64 + lane) * 16);
         if (row < rows_valid) *reinterpret_cast<uint4*>(out + ((uint32_t)row * ldo2 + (uint32_t)ch * 16u)) = v;
+        ch += 64 % NCH; row += 64 / NCH;
+        if (ch >= NCH) { ch -= NCH; row += 1; }
     }
 }
 

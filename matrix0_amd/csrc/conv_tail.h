@@ -14,6 +14,11 @@
 //      to the image, per-channel sums -> GroupNorm statistics of the wave's 10 groups by shuffles
 //   E  second pass over the image: y2 = act(y * scale + shift), 16-byte stores
 // Phases C-E touch only the wave's own image: no workgroup barrier after B.
+//
+// (The attention block's tail -- residual + LayerNorm over C + next GroupNorm -- was fused into the proj conv the same
+//  way, in the accumulator layout with DPP row reductions: correct, but 374 us against 92 + 228 us for proj +
+//  ew_board_kernel, because a row's LayerNorm statistics need cross-lane and cross-wave reductions and a per-element
+//  gather of x; not kept.)
 #pragma once
 #include "conv_epilogue.h"
 
@@ -231,3 +236,4 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
         }
     }
 }
+
