@@ -94,6 +94,7 @@ private:
     std::vector<void*> ws_allocs_;
 
     int C_ = 0, Cs_ = 0 /*ssl hidden padded*/;
+    int Cp_ = 0;   // trunk width in memory: C_, or 320 for 256 < C_ < 320 (zero-padded channels: the MFMA big-tile path)
     PackedGemm stem_;
     NormParams stem_n_;
     float* posenc_ = nullptr;
@@ -129,7 +130,8 @@ private:
 
     const HostTensor* get(const std::string& k, std::string& err);
     int pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
-                  int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err);
+                  int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads = 0,
+                  int qkv_heads_pad = 0);
     int upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err);
     float* upload_f32(const std::vector<float>& v);
     void* dalloc(size_t bytes, bool ws);

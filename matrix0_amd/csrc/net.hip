@@ -36,6 +36,7 @@ const char* Net::check_supported(const m0_net_cfg& c) {
 
 Net::Net(const m0_net_cfg& cfg, int device) : cfg_(cfg), device_(device) {
     C_ = cfg.channels;
+    Cp_ = (C_ > 256 && C_ < 320) ? 320 : C_;
     Cs_ = ceil_to(std::max(16, C_ / 2), 32);
     int k = cfg.attention_every_k;
     int stride = std::max(1, cfg.infer_attention_stride);
@@ -99,7 +100,7 @@ const HostTensor* Net::get(const std::string& k, std::string& err) {
 }
 
 int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
-                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err) {
+                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads, int qkv_heads_pad) {
     const HostTensor* w = get(wkey, err);
     if (!w) return M0_ERR_INVALID;
     size_t expect = (size_t)N_real * Cin_real * taps;
@@ -110,10 +111,15 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     const bool pp = KC == 64 && taps == 9;       // 3x3 big tile: conv_pp_kernel's half-tile layout
     const int nblk = N_pad / 320;
     std::vector<_Float16> p((size_t)taps * Cin_pad * N_pad, (_Float16)0.f);
-    for (int n = 0; n < N_real; ++n)
+    for (int nr = 0; nr < N_real; ++nr)
         for (int k = 0; k < Cin_real; ++k)
             for (int t = 0; t < taps; ++t) {
-                float v = w->data[((size_t)n * Cin_real + k) * taps + t];
+                float v = w->data[((size_t)nr * Cin_real + k) * taps + t];
+                int n = nr;
+                if (qkv_heads > 0) {           // qkv rows (t, head, dim) -> the same with the padded head count
+                    const int d = nr % 16, th = nr / 16, hh = th % qkv_heads, tt = th / qkv_heads;
+                    n = (tt * qkv_heads_pad + hh) * 16 + d;
+                }
                 int kk = k;
                 if (k_perm_ch > 0) {           // reference flatten index c*64+sq -> ours sq*Cp+c
                     int c = k / 64, sq = k % 64;
@@ -167,35 +173,35 @@ int Net::upload_norm(NormParams& n, const std::string& prefix, int C_real, int C
 int Net::finalize(std::string& err) {
     if (finalized_) return M0_OK;
     if (hipSetDevice(device_) != hipSuccess) { err = "hipSetDevice failed"; return M0_ERR_HIP; }
-    const int C = C_;
+    const int C = C_, P = Cp_;          // real / in-memory trunk width (padded channels carry zeros everywhere)
     nparams_ = 0;
-    TRY(pack_gemm(stem_, "stem.0.weight", "", 9, cfg_.planes, 32, C, C, 0, err));
-    TRY(upload_norm(stem_n_, "stem.1", C, C, err));
+    TRY(pack_gemm(stem_, "stem.0.weight", "", 9, cfg_.planes, 32, C, P, 0, err));
+    TRY(upload_norm(stem_n_, "stem.1", C, P, err));
     if (cfg_.chess_features) {
         const HostTensor* pe = get("chess_features.position_encoding", err);
         if (!pe) return M0_ERR_INVALID;
         if ((int)pe->data.size() != C * 64) { err = "shape mismatch for position_encoding"; return M0_ERR_INVALID; }
         nparams_ += pe->data.size();
-        std::vector<float> t((size_t)64 * C);
+        std::vector<float> t((size_t)64 * P, 0.f);
         for (int c = 0; c < C; ++c)
-            for (int n = 0; n < 64; ++n) t[(size_t)n * C + c] = pe->data[(size_t)c * 64 + n];
+            for (int n = 0; n < 64; ++n) t[(size_t)n * P + c] = pe->data[(size_t)c * 64 + n];
         posenc_ = upload_f32(t);
         if (cfg_.piece_square_tables) {
-            TRY(pack_gemm(pst_, "chess_features.pst_conv.weight", "", 1, C, C, C, C, 0, err));
-            TRY(upload_norm(pst_n_, "chess_features.pst_norm", C, C, err));
+            TRY(pack_gemm(pst_, "chess_features.pst_conv.weight", "", 1, C, P, C, P, 0, err));
+            TRY(upload_norm(pst_n_, "chess_features.pst_norm", C, P, err));
         }
-        TRY(pack_gemm(inter_, "chess_features.interaction_conv.weight", "", 9, C, C, C, C, 0, err));
-        TRY(upload_norm(inter_n_, "chess_features.interaction_norm", C, C, err));
+        TRY(pack_gemm(inter_, "chess_features.interaction_conv.weight", "", 9, C, P, C, P, 0, err));
+        TRY(upload_norm(inter_n_, "chess_features.interaction_norm", C, P, err));
     }
     int ti = 0;
     for (auto& L : tower_) {
         std::string p = "tower." + std::to_string(ti++);
         if (L.kind == 0) {
             ResBlockW& r = res_[L.index];
-            TRY(pack_gemm(r.conv1, p + ".conv1.weight", "", 9, C, C, C, C, 0, err));
-            TRY(pack_gemm(r.conv2, p + ".conv2.weight", "", 9, C, C, C, C, 0, err));
-            TRY(upload_norm(r.bn1, p + ".bn1", C, C, err));
-            TRY(upload_norm(r.bn2, p + ".bn2", C, C, err));
+            TRY(pack_gemm(r.conv1, p + ".conv1.weight", "", 9, C, P, C, P, 0, err));
+            TRY(pack_gemm(r.conv2, p + ".conv2.weight", "", 9, C, P, C, P, 0, err));
+            TRY(upload_norm(r.bn1, p + ".bn1", C, P, err));
+            TRY(upload_norm(r.bn2, p + ".bn2", C, P, err));
             if (cfg_.se) {
                 int hd = std::max(8, (int)(C * cfg_.se_ratio));
                 r.se_hidden = hd;
@@ -206,16 +212,18 @@ int Net::finalize(std::string& err) {
                 if ((int)w1->data.size() != hd * C || (int)w2->data.size() != hd * C || (int)b1->data.size() != hd ||
                     (int)b2->data.size() != C) { err = "shape mismatch for " + p + ".se_*"; return M0_ERR_INVALID; }
                 nparams_ += (size_t)2 * hd * C + hd + C;
-                std::vector<float> w1t((size_t)C * hd);       // [C][hd] from [hd][C]
+                std::vector<float> w1t((size_t)P * hd, 0.f);  // [P][hd] from [hd][C]
                 for (int j = 0; j < hd; ++j)
                     for (int c = 0; c < C; ++c) w1t[(size_t)c * hd + j] = w1->data[(size_t)j * C + c];
                 r.se_w1 = upload_f32(w1t);
                 r.se_b1 = upload_f32(b1->data);
-                std::vector<float> w2t((size_t)hd * C);       // [hd][C] from [C][hd]: coalesced across channels
+                std::vector<float> w2t((size_t)hd * P, 0.f);  // [hd][P] from [C][hd]: coalesced across channels
                 for (int c = 0; c < C; ++c)
-                    for (int j = 0; j < hd; ++j) w2t[(size_t)j * C + c] = w2->data[(size_t)c * hd + j];
+                    for (int j = 0; j < hd; ++j) w2t[(size_t)j * P + c] = w2->data[(size_t)c * hd + j];
                 r.se_w2 = upload_f32(w2t);
-                r.se_b2 = upload_f32(b2->data);
+                std::vector<float> b2p(P, 0.f);
+                std::copy(b2->data.begin(), b2->data.end(), b2p.begin());
+                r.se_b2 = upload_f32(b2p);
             }
         } else {
             AttnW& a = att_[L.index];
@@ -226,16 +234,16 @@ int Net::finalize(std::string& err) {
                 }
                 continue;
             }
-            TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, C, 3 * C, 3 * C, 0, err));
-            TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, C, C, C, 0, err));
-            TRY(upload_norm(a.ln, p + ".norm", C, C, err));
+            TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, P, 3 * C, 3 * P, 0, err, P != C ? cfg_.attention_heads : 0, P / 16));
+            TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, P, C, P, 0, err));
+            TRY(upload_norm(a.ln, p + ".norm", C, P, err));
             if (cfg_.attention_relbias) {
                 const HostTensor* rb = get(p + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
                 if ((int)rb->data.size() != cfg_.attention_heads * 4096) { err = "shape mismatch for rel_bias"; return M0_ERR_INVALID; }
                 nparams_ += rb->data.size();
                 {   // stored pre-multiplied by log2(e): the attention kernel exponentiates with exp2
-                    std::vector<float> rbs(rb->data);
-                    for (float& v : rbs) v *= 1.44269504088896f;
+                    std::vector<float> rbs((size_t)(P / 16) * 4096, 0.f);      // padded heads: zero bias
+                    for (size_t i = 0; i < rb->data.size(); ++i) rbs[i] = rb->data[i] * 1.44269504088896f;
                     a.rel_bias = upload_f32(rbs);
                 }
             }
@@ -256,7 +264,7 @@ int Net::finalize(std::string& err) {
         (void)hipMemcpy(mask_dev_, m.data(), 64 * 8, hipMemcpyHostToDevice);
     }
     // policy head
-    TRY(pack_gemm(ph_conv_, "policy_head.0.weight", "", 1, C, C, 64, 64, 0, err));
+    TRY(pack_gemm(ph_conv_, "policy_head.0.weight", "", 1, C_, Cp_, 64, 64, 0, err));
     TRY(upload_norm(ph_n_, "policy_head.1", 64, 64, err));
     if (cfg_.policy_factor_rank > 0) {
         int r = cfg_.policy_factor_rank, rp = ceil_to(r, 32);
@@ -273,7 +281,7 @@ int Net::finalize(std::string& err) {
         logit_scale_ = (float)std::min(5.0, sp + 1e-3);
     }
     // value head
-    TRY(pack_gemm(vh0_, "value_head.0.weight", "", 1, C, C, 128, 128, 0, err));
+    TRY(pack_gemm(vh0_, "value_head.0.weight", "", 1, C_, Cp_, 128, 128, 0, err));
     TRY(upload_norm(vh1_n_, "value_head.1", 128, 128, err));
     TRY(pack_gemm(vh3_, "value_head.3.weight", "", 1, 128, 128, 128, 128, 0, err));
     TRY(upload_norm(vh4_n_, "value_head.4", 128, 128, err));
@@ -293,7 +301,7 @@ int Net::finalize(std::string& err) {
             h.out_ch = kSslOut[t];
             h.hidden = C / 2;
             std::string p = std::string("ssl_heads.") + kSslNames[t];
-            TRY(pack_gemm(h.c0, p + ".0.weight", "", 1, C, C, C / 2, Cs_, 0, err));
+            TRY(pack_gemm(h.c0, p + ".0.weight", "", 1, C_, Cp_, C / 2, Cs_, 0, err));
             TRY(upload_norm(h.n, p + ".1", C / 2, Cs_, err));
             TRY(pack_gemm(h.c1, p + ".3.weight", "", 1, C / 2, Cs_, h.out_ch, 32, 0, err));
             ssl_.push_back(h);
@@ -341,7 +349,7 @@ int Net::ensure_workspace(int B, std::string& err) {
     (void)hipDeviceSynchronize();
     for (void* p : ws_allocs_) (void)hipFree(p);
     ws_allocs_.clear();
-    const size_t C = C_;
+    const size_t C = Cp_;
     const size_t nb = Bp, nh = std::max(Bp, Mfc);
     const size_t Cst = std::max<size_t>(C, 128);
     auto H = [&](size_t elems) { return (_Float16*)dalloc(elems * 2, true); };
@@ -451,7 +459,7 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
     const int Mfc = ceil_to(B, 256);
     const int act = cfg_.activation == M0_ACT_SILU ? ACT_SILU : ACT_RELU;
     const int vact = cfg_.value_activation == M0_ACT_SILU ? ACT_SILU : (cfg_.value_activation == M0_ACT_LEAKY ? ACT_LEAKY : ACT_RELU);
-    const int C = C_;
+    const int C = Cp_;                 // in-memory trunk width
 
     const _Float16* x0 = nhwc_dev;
     if (!x0) {
@@ -477,7 +485,7 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             e.gate = G_;
         }
         e.res = res; e.posenc = pos;
-        if (ln) { e.ln_g = ln->gamma; e.ln_b = ln->beta; }
+        if (ln) { e.ln_g = ln->gamma; e.ln_b = ln->beta; e.ln_count = C_; }
         e.y = y; e.out_stats = ost; e.C = Cc; e.act = act; e.stats_from_rounded = 0;
         if (next_bn1 && y2) { e.y2 = y2; e.gn2_gamma = next_bn1->gamma; e.gn2_beta = next_bn1->beta; }
         return launch_ew_board(e, boards, st);
@@ -544,8 +552,8 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             KCHK(run_gemm(w.qkv, xa, QKV_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             AttnArgs aa;
             aa.qkv = QKV_; aa.rel_bias = w.rel_bias; aa.mask = mask_dev_; aa.o = O_;
-            aa.B = Bp; aa.H = cfg_.attention_heads; aa.C = C; aa.mix = cfg_.attention_unmasked_mix;
-            aa.inv_sqrt_d = 1.f / sqrtf((float)(C / cfg_.attention_heads));
+            aa.B = Bp; aa.H = C / 16; aa.C = C; aa.mix = cfg_.attention_unmasked_mix;      // head_dim 16; padded heads are all-zero
+            aa.inv_sqrt_d = 1.f / sqrtf((float)(C_ / cfg_.attention_heads));
             KCHK(launch_attn_core(aa, st));
             KCHK(run_gemm(w.proj, O_, T1_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             KCHK(ew(T1_, nullptr, nullptr, nullptr, xa, nullptr, &w.ln, xb, nullptr, next_bn1_after(li), AA_, C, Bp));

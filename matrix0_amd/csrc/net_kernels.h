@@ -43,8 +43,9 @@ struct EwArgs {
     const float* gate;       // [B][C] squeeze-excite gate (se_gate_kernel), applied when non-null (and gn null)
     const _Float16* res;     // [B][64][C] or null
     const float* posenc;     // [64][C] or null
-    const float* ln_g;       // LayerNorm over C when non-null
+    const float* ln_g;       // LayerNorm over the first ln_count channels when non-null (the rest are zero padding)
     const float* ln_b;
+    int ln_count;            // 0: C
     _Float16* y;             // [B][64][C]
     float* out_stats;        // [B][C][2] or null
     _Float16* y2;            // [B][64][C] or null: act(GroupNorm16(y; gn2_*)), the next block's conv1 input

@@ -362,8 +362,9 @@ __global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) { rs += __shfl_xor(rs, o); rss += __shfl_xor(rss, o); }
             if (p8 == 0) {
-                const float mean = rs / (float)C;
-                float var = rss / (float)C - mean * mean;
+                const float cnt = (float)(a.ln_count > 0 ? a.ln_count : C);
+                const float mean = rs / cnt;
+                float var = rss / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 rowp[sq] = make_float2(mean, rsqrtf(var + 1e-5f));
             }

@@ -108,6 +108,32 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
             assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
 
 
+def test_shipped_config_288x22_zero_padded_trunk():
+    """The reference's shipped config.yaml network (288 channels x 22 blocks, 18 heads, rank-160 policy, attention
+    stride 2, leaky value head): the engine zero-pads its trunk to 320 channels so it runs on the MFMA big-tile kernels;
+    padded channels must stay exactly zero through GroupNorm / squeeze-excite / attention / LayerNorm."""
+    from matrix0_amd.backend import M0Backend
+    cfg = dict(planes=19, channels=288, blocks=22, attention=True, attention_heads=18, policy_size=4672, norm="group",
+               activation="silu", value_activation="leaky_relu", preact=True, policy_factor_rank=160,
+               infer_attention_stride=2, self_supervised=True, ssl_tasks=["piece", "threat", "pin", "fork", "control"])
+    sd = net_ref.random_state_dict(cfg, seed=0)
+    be = M0Backend.from_state_dict(cfg, sd)
+    assert be.param_count() == 44_193_314
+    g = torch.Generator().manual_seed(5)
+    B = 5
+    x = torch.zeros(B, 19, 8, 8)
+    x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+    x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+    x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+    p_ref, v_ref, ssl_ref = net_ref.forward(sd, cfg, x, return_ssl=True)
+    p, v, ssl = be.infer_np_ssl(x.numpy())
+    assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
+    assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
+    assert _kl(p_ref.numpy(), p) <= 1e-3
+    for t in ssl_ref:
+        assert np.abs(ssl[t] - ssl_ref[t].numpy()).max() <= 1e-1, t
+
+
 def test_infer_np_rejects_bad_shape_and_nan():
     from matrix0_amd.backend import M0Backend
     cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
