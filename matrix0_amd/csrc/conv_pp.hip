@@ -294,7 +294,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     asm volatile("" :: "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]), "v"(acc[1][4]));
 #else
     // every wave is past its last LDS read and DMA wait here (the barrier just above / the loop's final one)
-    if constexpr (EPI == 3) conv_tail_epilogue<ACT>(acc, a, smem, m0, wm, wn, wave, lane);
+    if constexpr (EPI == 3) conv_tail_epilogue<ACT, false>(acc, a, smem, m0, wm, wn, wave, lane);
+    else if constexpr (EPI == 5) conv_tail_epilogue<ACT, true>(acc, a, smem, m0, wm, wn, wave, lane);
     else conv_tile_epilogue<EPI, ACT, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
 #endif
 }
@@ -323,6 +324,12 @@ hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st) {
         if (a.N != 320 || a.Npad != 320 || a.ldo != 320 || a.bias != nullptr || a.out_stats != nullptr) return hipErrorInvalidValue;
         if (a.y2 != nullptr && a.gn_gamma == nullptr) return hipErrorInvalidValue;
         if (a.se_w1 != nullptr && (a.se_hidden < 4 || a.se_hidden > 128 || a.se_hidden % 4 != 0)) return hipErrorInvalidValue;
+        if (a.pre_gamma != nullptr) {               // x += act(norm(conv(x))) (chess-feature conv) + next GroupNorm
+            if (a.se_w1 != nullptr) return hipErrorInvalidValue;
+            if (a.epi_act == ACT_SILU) return launch_conv_pp_e<5, ACT_SILU>(a, st);
+            if (a.epi_act == ACT_RELU) return launch_conv_pp_e<5, ACT_RELU>(a, st);
+            return hipErrorInvalidValue;
+        }
         if (a.epi_act == ACT_SILU) return launch_conv_pp_e<3, ACT_SILU>(a, st);
         if (a.epi_act == ACT_RELU) return launch_conv_pp_e<3, ACT_RELU>(a, st);
         return hipErrorInvalidValue;

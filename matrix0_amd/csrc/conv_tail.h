@@ -28,7 +28,9 @@ __device__ __forceinline__ void tail_glds16(const void* gsrc, void* lds_wave_bas
 }
 
 // C == 320 (one N block), 8 waves: wave = (board wm, channel half wn), NT == 5.
-template <int ACT>
+// PRE: t is first normalised and activated, t <- act(GroupNorm16(t; a.pre_gamma, a.pre_beta)) -- the chess-feature
+// convs (resnet.py:229-244: x += act(norm(conv(x)))); no squeeze-excite in that case.
+template <int ACT, bool PRE = false>
 __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const GemmArgs& a, char* smem, int m0, int wm,
                                                    int wn, int wave, int lane) {
     constexpr int NT = 5, C = 320;
@@ -59,7 +61,7 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
 #ifdef TAIL_NO_SE
     if (false) {
 #else
-    if (se) {
+    if (se && !PRE) {
 #endif
         const int wbytes = C * Hd * 4;                          // multiple of 1024 (C = 320)
         const int npieces = wbytes >> 10;
@@ -133,6 +135,27 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
     } else {
         static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) { gv[decltype(ni_)::value] = 1.f; });
     }
+    float pv[NT];                                                 // PRE: per-column shift (gv = scale)
+    if constexpr (PRE) {
+        // GroupNorm(16 channels x 64 squares) of t on the accumulators: the wave owns whole groups (as EPI 1)
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            const int col = wn * 160 + ni * 32 + r31;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                const float16v av = acc[decltype(mi_)::value][ni];
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+            });
+#pragma unroll
+            for (int o = 1; o <= 8; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            const float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            gv[ni] = rsqrtf(var + 1e-5f) * a.pre_gamma[col];
+            pv[ni] = a.pre_beta[col] - mean * gv[ni];
+        });
+    }
 
     // C: gate * t -> the wave's fp16 image; the loads of x are issued between the tile columns, into the registers
     // the staged accumulators free (x is 2-3 us away and nothing else runs on this CU)
@@ -153,7 +176,8 @@ __device__ __forceinline__ void conv_tail_epilogue(float16v (&acc)[2][5], const 
             float v[16];
             static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
                 constexpr int r = decltype(r_)::value;
-                v[r] = acc[mi][ni][r] * gv[ni];
+                if constexpr (PRE) v[r] = act_fast<ACT>(acc[mi][ni][r] * gv[ni] + pv[ni]);
+                else v[r] = acc[mi][ni][r] * gv[ni];
             });
             conv_stage_tile<NT, mi, ni>(v, wbase, lane);
         });

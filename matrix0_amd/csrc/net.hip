@@ -468,6 +468,9 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         x0 = X0_;
     }
     const bool big = conv_gemm_tile_n(C, C) == 320;     // fused GN epilogue available (C % 320 == 0)
+    const char* ftenv = getenv("M0_FUSE_TAIL");          // =0: conv2 + se_gate + ew_board as separate kernels
+    const bool fuse_tail = big && C == 320 && !(ftenv && ftenv[0] == '0') &&
+                           (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
     // ew: elementwise glue; y2/gn2 = pre-activated input of the NEXT residual block (its bn1), or null
     auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
                   const float* pos, const NormParams* ln, _Float16* y, float* ost, const NormParams* next_bn1,
@@ -516,16 +519,25 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, nullptr, nullptr, C, Bp));
             std::swap(xa, xb);
         }
-        KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-        KCHK(ew(T1_, S1_, &inter_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, first_bn1, AA_, C, Bp));
+        if (fuse_tail) {
+            // interaction conv + GroupNorm/act + residual add + the first block's GroupNorm/act in one kernel
+            GemmArgs ia;
+            memset(&ia, 0, sizeof(ia));
+            ia.in = xa; ia.w = inter_.w; ia.out = xb;
+            ia.Mrows = Mc; ia.Mvalid = Mc; ia.Cin = inter_.Cin; ia.N = inter_.N; ia.Npad = inter_.N; ia.ldo = inter_.N;
+            ia.epi_act = act; ia.out_scale = 1.f; ia.w_pp = inter_.pp ? 1 : 0;
+            ia.res = xa; ia.pre_gamma = inter_n_.gamma; ia.pre_beta = inter_n_.beta;
+            if (first_bn1) { ia.y2 = AA_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; }
+            KCHK(launch_conv_gemm(ia, 9, st));
+        } else {
+            KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+            KCHK(ew(T1_, S1_, &inter_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, first_bn1, AA_, C, Bp));
+        }
         std::swap(xa, xb);
     } else {
         KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, nullptr, nullptr, xa, nullptr, first_bn1, AA_, C, Bp));
     }
     // tower
-    const char* ftenv = getenv("M0_FUSE_TAIL");          // =0: conv2 + se_gate + ew_board as separate kernels
-    const bool fuse_tail = big && C == 320 && !(ftenv && ftenv[0] == '0') &&
-                           (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
     for (size_t li = 0; li < tower_.size(); ++li) {
         const TowerLayer& L = tower_[li];
         if (L.kind == 0) {

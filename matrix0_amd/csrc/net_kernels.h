@@ -27,6 +27,8 @@ struct GemmArgs {
     // residual-block tail fused into the epilogue (conv_tail.h), when res != null: out = res + gate * conv,
     // y2 = epi_act(GroupNorm16(out; gn_gamma, gn_beta)) when y2 != null, gate from se_* when se_w1 != null
     const _Float16* res;     // [Mrows][ldo]
+    const float* pre_gamma;  // with res: conv output first through act(GroupNorm16(.; pre_gamma, pre_beta)) (no gate)
+    const float* pre_beta;
     _Float16* y2;            // [Mrows][ldo] or null
     const float* se_w1;      // [C][Hd] (transposed)
     const float* se_b1;
