@@ -191,6 +191,15 @@ def main():
             games_per_s = (sims / dt_max) / (args.sims * ppg)
             basis = f"simulations/s / ({args.sims} sims per move x {ppg:.1f} plies per game [{basis_src}])"
         achieved = (conv_flop / (conv_ms * 1e-3)) if conv_ms > 0 else 0.0
+        # launch mix: conv2 of every block (and the interaction conv) also carries the fused block tail
+        tail_ms, tail_n = getattr(be, "last_tail_profile", (0.0, 0))
+        plain_n = conv_launches - tail_n
+        flop_per_launch = conv_flop / conv_launches if conv_launches else 0.0
+        mix = {"with_fused_tail": {"launches": int(tail_n), "avg_launch_us": (tail_ms * 1e3 / tail_n) if tail_n else None,
+                                   "achieved": (flop_per_launch / (tail_ms * 1e-3 / tail_n) / 1e12) if tail_n else None},
+               "conv_only": {"launches": int(plain_n),
+                             "avg_launch_us": ((conv_ms - tail_ms) * 1e3 / plain_n) if plain_n else None,
+                             "achieved": (flop_per_launch / ((conv_ms - tail_ms) * 1e-3 / plain_n) / 1e12) if plain_n else None}}
         traffic = None
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))["hbm_bytes_per_launch"]
@@ -213,6 +222,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
                          "launches": int(conv_launches), "avg_launch_us": (conv_ms * 1e3 / conv_launches) if conv_launches else None,
+                         "launch_mix": mix,
                          "whole_net_frac": (evals * flops_eval / dt_max) / (PEAK_FP16_DENSE * args.gpus)},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -101,6 +101,9 @@ int m0_net_bench_forward(m0_net* net, int B, int iters, int with_ssl, float* ms_
  * (2 * rows * Cout * Cin * 9 per launch) and launches since the last reset. */
 int m0_net_profile_enable(m0_net* net, int on);
 int m0_net_profile_get(m0_net* net, double* conv_ms, double* conv_flop, int64_t* launches, int reset);
+/* Of those, the milliseconds and launches of the convs that also carry a fused block tail (conv2 of every residual
+ * block, the interaction conv); call before a resetting m0_net_profile_get. */
+int m0_net_profile_get_tail(m0_net* net, double* tail_ms, int64_t* tail_launches);
 
 
 /* ---- position-wise azchess/encoding.py on the device (batched) ----

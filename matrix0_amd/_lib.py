@@ -70,6 +70,7 @@ def lib():
     L.m0_net_bench_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.m0_net_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.m0_net_profile_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    L.m0_net_profile_get_tail.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
     return L
 

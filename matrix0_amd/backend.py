@@ -125,6 +125,9 @@ class M0Backend:
     def profile_get(self, reset: bool = False):
         """(ms, algorithmic FLOP, launches) of the 3x3 conv kernel, HIP events on its launch stream."""
         ms, fl, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        tms, tn = C.c_double(0), C.c_int64(0)
+        _lib.check(self._L.m0_net_profile_get_tail(self._h, C.byref(tms), C.byref(tn)), "m0_net_profile_get_tail")
+        self.last_tail_profile = (tms.value, tn.value)      # (ms, launches) of the convs with a fused block tail
         _lib.check(self._L.m0_net_profile_get(self._h, C.byref(ms), C.byref(fl), C.byref(n), int(reset)), "m0_net_profile_get")
         return ms.value, fl.value, n.value
 

@@ -159,6 +159,14 @@ int m0_net_profile_get(m0_net* n, double* conv_ms, double* conv_flop, int64_t* l
     return M0_OK;
 }
 
+int m0_net_profile_get_tail(m0_net* n, double* tail_ms, int64_t* tail_launches) {
+    if (!n) { m0_set_error("net is null"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(n->mu);
+    if (tail_ms) *tail_ms = n->net->prof_tail_ms();
+    if (tail_launches) *tail_launches = n->net->prof_tail_launches();
+    return M0_OK;
+}
+
 int m0_net_bench_forward(m0_net* n, int B, int iters, int with_ssl, float* ms_per_forward) {
     if (!n || !ms_per_forward || B <= 0 || iters <= 0) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(n->mu);

@@ -82,7 +82,9 @@ public:
     double prof_conv_ms() const { return prof_ms_; }
     double prof_conv_flop() const { return prof_flop_; }
     long prof_conv_launches() const { return prof_launches_; }
-    void reset_profile() { prof_ms_ = 0; prof_flop_ = 0; prof_launches_ = 0; }
+    void reset_profile() { prof_ms_ = 0; prof_flop_ = 0; prof_launches_ = 0; prof_tail_ms_ = 0; prof_tail_launches_ = 0; }
+    double prof_tail_ms() const { return prof_tail_ms_; }          // the part of the above spent in launches with a fused tail
+    long prof_tail_launches() const { return prof_tail_launches_; }
 
 private:
     m0_net_cfg cfg_;
@@ -114,9 +116,10 @@ private:
     bool profile_ = false;
     std::vector<hipEvent_t> pev_;
     std::vector<double> pflop_;
+    std::vector<char> ptail_;
     size_t pev_used_ = 0;
-    double prof_ms_ = 0, prof_flop_ = 0;
-    long prof_launches_ = 0;
+    double prof_ms_ = 0, prof_flop_ = 0, prof_tail_ms_ = 0;
+    long prof_launches_ = 0, prof_tail_launches_ = 0;
 
     // workspace
     int wsB_ = 0, wsM_ = 0;

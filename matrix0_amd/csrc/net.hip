@@ -398,6 +398,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
         (void)hipEventRecord(pev_[pev_used_ + 1], st);
         pev_used_ += 2;
         pflop_.push_back(2.0 * (double)Mvalid * (double)g.N * (double)g.Cin * 9.0);
+        ptail_.push_back(0);
     }
     return rc;
 }
@@ -425,6 +426,7 @@ hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Flo
         (void)hipEventRecord(pev_[pev_used_ + 1], st);
         pev_used_ += 2;
         pflop_.push_back(2.0 * (double)Mrows * (double)g.N * (double)g.Cin * 9.0);
+        ptail_.push_back(1);
     }
     return rc;
 }
@@ -434,10 +436,12 @@ void Net::harvest_profile() {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pev_[i], pev_[i + 1]) == hipSuccess) {
             prof_ms_ += ms; prof_flop_ += pflop_[i / 2]; prof_launches_++;
+            if (ptail_[i / 2]) { prof_tail_ms_ += ms; prof_tail_launches_++; }
         }
     }
     pev_used_ = 0;
     pflop_.clear();
+    ptail_.clear();
 }
 
 #define KCHK(x)                                                                           \
