@@ -23,7 +23,7 @@ import numpy as np
 
 from . import encoding
 from .backend import M0Backend
-from .data_writer import SelfplayShardWriter
+from .data_writer import ReplayShardWriter, SelfplayShardWriter
 from .engine import SelfplayEngine, selfplay_cfg_from_dict
 from .weights import random_state_dict
 
@@ -67,7 +67,14 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                                   virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
                                   ssl_targets=bool(ssl_tasks))
     engine = SelfplayEngine(backend, scfg)
-    writer = SelfplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"))
+    # engine.replay_shards: emit replay-buffer shards directly (ReplayShardWriter: what the orchestrator's
+    # compact_selfplay_to_replay would make of the per-game files) instead of one NPZ per game
+    direct_replay = bool(eng_cfg.get("replay_shards", False))
+    if direct_replay:
+        writer = ReplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"),
+                                   max_shards=int(eng_cfg.get("max_shards", 128)), shard_size=int(eng_cfg.get("shard_size", 16384)))
+    else:
+        writer = SelfplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"))
     last_hb = time.perf_counter()
     done = 0
     try:
@@ -91,7 +98,11 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                 for task in ssl_tasks:                              # internal.py:647-651
                     if "ssl" in rec and task in rec["ssl"]:
                         game_data[f"ssl_{task}"] = rec["ssl"][task].astype(np.float32)
-                filepath = writer.add_selfplay_data(game_data, worker_id=proc_id, game_id=rec["game_index"]) if T > 0 else None
+                filepath = None
+                if T > 0 and direct_replay:
+                    writer.add_game(game_data)
+                elif T > 0:
+                    filepath = writer.add_selfplay_data(game_data, worker_id=proc_id, game_id=rec["game_index"])
                 done += 1
                 if q is not None:                                   # internal.py:665-679
                     q.put({"type": "game", "proc": proc_id, "file": filepath, "moves": T, "result": z,
@@ -106,5 +117,7 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                        "avg_policy_entropy": 0.0})
                 last_hb = now
     finally:
+        if direct_replay:
+            writer.close()                                          # tail shard + pruning
         engine.close()
         backend.close()
