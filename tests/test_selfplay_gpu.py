@@ -127,6 +127,35 @@ def test_drop_in_worker_writes_shards_and_queue_messages(tmp_path):
     assert n[0] == 4 and n[1] == sum(m["moves"] for m in games)
 
 
+def test_worker_direct_replay_shards(tmp_path):
+    """engine.replay_shards: the worker writes replay-buffer shards (data_manager.py:245-262, 1378-1493 format)
+    instead of one NPZ per game; the samples are the games' rows in completion order."""
+    import queue
+    import sqlite3
+    from matrix0_amd.selfplay import selfplay_worker
+    cfg = dict(CFG, model=NET, data_dir=str(tmp_path),
+               engine={"concurrent_games": 3, "leaves_per_step": 8, "replay_shards": True, "shard_size": 32})
+    q = queue.Queue()
+    selfplay_worker(0, cfg, None, 4, q, None)
+    games = []
+    while not q.empty():
+        m = q.get()
+        if m["type"] == "game":
+            games.append(m)
+    assert len(games) == 4 and all(m["file"] is None for m in games)
+    total = sum(m["moves"] for m in games)
+    assert not list((tmp_path / "selfplay").glob("*.npz"))
+    shards = sorted((tmp_path / "replays").glob("replays_*.npz"))
+    sizes = sorted(np.load(p)["s"].shape[0] for p in shards)
+    assert sum(sizes) == total and all(n == 32 for n in sizes[1:]) and 0 < sizes[0] <= 32
+    for p in shards:
+        z = np.load(p)
+        assert set(z.files) == {"s", "pi", "z", "legal_mask"} and z["legal_mask"].dtype == np.uint8
+        np.testing.assert_allclose(z["pi"].sum(axis=1), 1.0, atol=1e-3)
+    rows = sqlite3.connect(str(tmp_path / "data_metadata.db")).execute("SELECT sum(sample_count), count(*) FROM shards").fetchone()
+    assert rows[0] == total and rows[1] == len(shards)
+
+
 def test_baseline_config0_one_game_64_sims_full_size_net():
     """BASELINE configs[0] as a parity case: 1 self-play game, 64 sims/move, random-init R24-320 (the reference's
     CPU-runnable case), here on the GPU; the game is replayed through the oracle's rules and encoder."""
