@@ -134,6 +134,31 @@ def test_shipped_config_288x22_zero_padded_trunk():
         assert np.abs(ssl[t] - ssl_ref[t].numpy()).max() <= 1e-1, t
 
 
+def test_full_size_batch_invariance_and_determinism():
+    """Size-independent properties at the benchmark batch size: a board's outputs do not depend on which other boards
+    share its launch (4-board tiles, per-board statistics), nor on the run -- 4096 boards in one call, the same boards
+    in ragged chunks, and a repeat must agree bit for bit."""
+    from matrix0_amd.backend import M0Backend
+    cfg = _r24_cfg()
+    be = M0Backend.from_state_dict(cfg, net_ref.random_state_dict(cfg, seed=0))
+    rng = np.random.default_rng(7)
+    B = 4096
+    x = np.zeros((B, 19, 8, 8), np.float32)
+    x[:, :12] = (rng.random((B, 12, 8, 8)) < 0.08).astype(np.float32)
+    x[:, 12:17] = (rng.random((B, 5, 1, 1)) < 0.5).astype(np.float32)
+    x[:, 17:] = rng.random((B, 2, 1, 1)).astype(np.float32)
+    p_all, v_all = be.infer_np(x)
+    assert np.isfinite(p_all).all() and np.isfinite(v_all).all() and np.abs(v_all).max() <= 1.0
+    p_rep, v_rep = be.infer_np(x)
+    assert np.array_equal(p_all, p_rep) and np.array_equal(v_all, v_rep)
+    start = 0
+    for n in (1, 3, 254, 1000, 2838):                  # ragged chunk sizes summing to 4096
+        p, v = be.infer_np(x[start:start + n])
+        assert np.array_equal(p, p_all[start:start + n]) and np.array_equal(v, v_all[start:start + n]), (start, n)
+        start += n
+    assert start == B
+
+
 def test_infer_np_rejects_bad_shape_and_nan():
     from matrix0_amd.backend import M0Backend
     cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
