@@ -156,6 +156,56 @@ def test_worker_direct_replay_shards(tmp_path):
     assert rows[0] == total and rows[1] == len(shards)
 
 
+def test_full_size_configuration_properties():
+    """BASELINE configs[1] at full size -- 256 concurrent games, 800 simulations per move, R24-320, 16 leaves per tree and
+    step -- cut to 2 searched plies per game: the invariants that do not depend on size.  Every searched ply spent
+    exactly its simulation budget (800, or the reduced playout cap), pi is the normalised visit distribution over
+    legal moves only, every played move is legal and was visited, planes/masks equal the oracle's on replay."""
+    import bench
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.SELFPLAY_CFG.items()}
+    cfgd["selfplay"] = dict(cfgd["selfplay"], max_game_len=2)
+    be = M0Backend.from_state_dict(bench.R24_320, net_ref.random_state_dict(bench.R24_320, seed=0))
+    cfg = eng.selfplay_cfg_from_dict(cfgd, concurrent_games=256, total_games=256, leaves_per_step=16,
+                                     virtual_loss_active=True, record_games=True)
+    e = eng.SelfplayEngine(be, cfg)
+    games = []
+    for _ in range(400):
+        e.step(10)
+        while (r := e.poll()) is not None:
+            games.append(r)
+        if not e.running():
+            break
+    st = e.stats()
+    assert len(games) == 256 and st["games_finished"] == 256
+    assert sorted(g["game_index"] for g in games) == list(range(256))
+    sims = int(cfgd["selfplay"]["num_simulations"])
+    assert sims == 800
+    total_plies = sum(g["moves"] for g in games)
+    assert st["plies"] == total_plies
+    # every search spends its whole budget: 800 simulations, or the reduced playout cap on ~5% of the plies
+    assert st["sims"] <= sims * total_plies and st["sims"] >= 0.9 * sims * total_plies
+    for g in games:
+        T = g["moves"]
+        assert 1 <= T <= 2
+        np.testing.assert_allclose(g["pi"].sum(axis=1), 1.0, atol=1e-4)
+        assert np.all(g["pi"] >= 0) and np.all(g["pi"][g["legal_mask"] == 0] == 0)
+        assert np.all(np.abs(g["z"]) <= 1.0)
+        b = ch.Board()
+        played = [ch.Move.from_uci(u) for u in g["played"]]
+        n_open = len(played) - (T - (1 if g["resigned"] else 0))
+        assert 0 <= n_open <= 12
+        for i, m in enumerate(played):
+            assert m in b.legal_moves, (i, m)
+            if i >= n_open:
+                t = i - n_open
+                assert np.array_equal(g["s"][t], ch.encode_board(b))
+                assert np.array_equal(g["legal_mask"][t].astype(bool), ch.get_legal_actions(b))
+                assert g["pi"][t][ch.move_to_index(b, m)] > 0
+            b.push(m)
+
+
 def test_baseline_config0_one_game_64_sims_full_size_net():
     """BASELINE configs[0] as a parity case: 1 self-play game, 64 sims/move, random-init R24-320 (the reference's
     CPU-runnable case), here on the GPU; the game is replayed through the oracle's rules and encoder."""
