@@ -154,6 +154,10 @@ typedef struct m0_selfplay_cfg {
     int ssl_in_forward;           /* run the SSL heads in every leaf evaluation (BASELINE config 4) */
     int ssl_targets;              /* generate ssl_* target maps for every recorded ply (selfplay/internal.py:460-482) */
     int record_games;             /* keep s/pi/legal_mask per ply for m0_selfplay_poll */
+    /* evaluation matches (azchess/arena.py:59-126), m0_arena_create only */
+    int arena_mode;               /* set by m0_arena_create */
+    double arena_temp;            /* move choice: softmax(log(visits+1e-8)/temp) for the first arena_temp_plies plies ... */
+    int arena_temp_plies;         /* ... then (or with temp <= 1e-3) the most visited move, first maximum in move order */
 } m0_selfplay_cfg;
 
 typedef struct m0_selfplay m0_selfplay;
@@ -193,6 +197,23 @@ int m0_selfplay_poll(m0_selfplay* sp, m0_game_record* out);
 void m0_game_record_free(m0_game_record* rec);
 /* 1 while games remain to be played or are in flight. */
 int m0_selfplay_running(m0_selfplay* sp);
+
+/* Evaluation match between two networks (azchess/arena.py:59-126 _arena_run_one_game, :305 play_match): game i is played
+ * with net_a as White when i is even.  Every search of a game is evaluated by the network of the side to move; each
+ * move starts a fresh tree (the reference keeps one MCTS object, hence one transposition table, per side -- a subtree is
+ * not carried from one side's search to the other's).  The game ends on board.is_game_over(claim_draw=True), on
+ * cfg->max_game_len plies or on draw adjudication (draw.py); no resignation.  Step / poll / stats / destroy with the
+ * m0_selfplay_* functions; a record's `played` holds the moves, `result` the outcome from White's point of view
+ * (0 for unfinished or adjudicated games, as the reference scores them 1/2-1/2). */
+m0_selfplay* m0_arena_create(m0_net* net_a, m0_net* net_b, const m0_selfplay_cfg* cfg);
+/* PGN output of arena games (arena.py:281-303 uses chess.pgn): standard algebraic notation, python-chess Board.san().
+ * m0_san_legal_fen: the legal moves of `fen` in legal_moves order (moves u16[256]) with their SAN (san char[256][8],
+ * NUL-padded).  m0_san_game: movetext "1. e4 e5 2. Nf3 ..." of a game from the start position (moves as in
+ * m0_game_record.played); returns its length. */
+/* arena.py:73-106 move choice over a visit list in move order; u = the uniform np.random.choice would draw. */
+int m0_arena_choose_move(const int32_t* visits, int n, double temp, int ply, int temp_plies, double u);
+int m0_san_legal_fen(const char* fen, uint16_t* moves, char* san, int* nlegal);
+int m0_san_game(const uint16_t* moves, int n, char* out, int cap);
 
 /* ---- split-step search (external evaluator / parity tests): net may be NULL ----
  * m0_search_begin: reset slot g to `fen` (history-less), sims simulations, optional Dirichlet.

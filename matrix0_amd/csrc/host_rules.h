@@ -197,6 +197,28 @@ inline int sample_move_index(const int32_t* visits, int n, double temperature, d
     return n - 1;
 }
 
+// arena move choice (arena.py:73-86, 106): float32 logits = log(visits + 1e-8) / max(temp, 1e-3), softmax, then
+// np.random.choice(p=probs) = inverse CDF on u; temp <= 1e-3 or ply >= temp_plies: most visited, first maximum
+inline int arena_choose_move(const int32_t* visits, int n, double temp, int ply, int temp_plies, double u) {
+    int best = 0;
+    for (int i = 1; i < n; ++i) if (visits[i] > visits[best]) best = i;
+    if (!(temp > 1e-3 && ply < temp_plies)) return best;
+    std::vector<float> lg(n), pr(n);
+    const float t = (float)(temp > 1e-3 ? temp : 1e-3);
+    float mx = -INFINITY;
+    for (int i = 0; i < n; ++i) { lg[i] = logf((float)visits[i] + 1e-8f) / t; if (lg[i] > mx) mx = lg[i]; }
+    for (int i = 0; i < n; ++i) pr[i] = expf(lg[i] - mx);
+    const float s = np_sum_f32(pr.data(), n);
+    if (!(s > 0.f) || !std::isfinite(s)) return best;
+    double cum = 0.0;
+    std::vector<double> cdf(n);
+    for (int i = 0; i < n; ++i) { pr[i] = pr[i] / s; cum += (double)pr[i]; cdf[i] = cum; }
+    const double last = cdf[n - 1];
+    for (int i = 0; i < n; ++i)
+        if (cdf[i] / last > u) return i;
+    return n - 1;
+}
+
 struct ResignState {
     int consec_bad = 0;
     std::vector<double> recent_values, recent_entropies;

@@ -50,6 +50,7 @@ struct HostGame {
     HStream rng;                          // PURPOSE_GAME stream: opening plies, playout cap, move sampling
     double t0 = 0.0;
     int cur_sims = 0;
+    bool a_is_white = true;               // arena
 };
 
 }  // namespace
@@ -59,6 +60,7 @@ struct m0_selfplay {
     TreeCfg tc;
     m0_net* nethandle = nullptr;
     Net* net = nullptr;
+    Net* net_b = nullptr;                 // arena: the second network (games with an odd index play it as White)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -82,6 +84,7 @@ struct m0_selfplay {
     std::vector<Sample> hsamples;
     std::vector<int> prev_done;           // per slot: simulations already credited to stats.sims
     int last_rows = 0;
+    int rows2[2] = {0, 0};                // rows of the last select per network
 };
 
 namespace {
@@ -154,6 +157,7 @@ void start_game(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::vecto
     parse_fen("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", hgm.pos);
     hgm.rng = HStream(derive_seed(sp->cfg.seed, hgm.game_index, PURPOSE_GAME));
     hgm.t0 = now_ms();
+    hgm.a_is_white = (hgm.game_index % 2) == 0;               // arena.py:66
     seed_game_dev(sp->hg[slot], sp->cfg.seed, hgm.game_index);
     sp->hg[slot].evals = 0;
     // opening diversity: uniform random legal plies (internal.py:366-379; random.choice -> injected stream)
@@ -176,10 +180,16 @@ void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv
     HostGame& hgm = sp->games[slot];
     const m0_selfplay_cfg& c = sp->cfg;
     DrawCfg dc = draw_cfg_from(c);
-    if (is_game_over(hgm.pos, hgm.win, false) || hgm.nstates >= c.max_game_len ||
+    // self-play: internal.py:382-408; arena: `while not board.is_game_over(claim_draw=True) and moves < max_moves`
+    // then the adjudication test (arena.py:68-72)
+    if (is_game_over(hgm.pos, hgm.win, c.arena_mode != 0) || hgm.nstates >= c.max_game_len ||
         should_adjudicate_draw(hgm.pos, hgm.win, hgm.history, dc)) {
         finish_game(sp, slot, false, 0, false, 0.f);
         return;
+    }
+    if (c.arena_mode) {
+        child_slot = -1;                                           // a fresh tree per move (see m0_arena_create)
+        sp->hg[slot].net_id = ((hgm.pos.turn == WHITE) == hgm.a_is_white) ? 0 : 1;
     }
     int sims = playout_cap(c.num_simulations, c.playout_random_frac, hgm.rng.next());
     hgm.cur_sims = sims;
@@ -196,10 +206,11 @@ void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool ha
     if (!have_z) {
         // internal.py:587-599 computed per game (SURVEY B-8: the reference's stale-z reuse is not reproduced)
         if (is_game_over(hgm.pos, hgm.win, true)) z = game_result(hgm.pos);
+        else if (c.arena_mode) z = 0.f;                              // arena.py:121-123: unfinished = 1/2-1/2
         else z = hgm.search_values.empty() ? 0.f : hgm.search_values.back();
     }
     sp->stats.games_finished++;
-    if (c.record_games && hgm.nstates > 0) {
+    if ((c.record_games && hgm.nstates > 0) || c.arena_mode) {
         GameRecordOwner* o = new GameRecordOwner();
         o->s.swap(hgm.states); o->pi.swap(hgm.pis); o->legal_mask.swap(hgm.masks);
         o->search_values = hgm.search_values;
@@ -283,7 +294,13 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
     double temp = temperature_for(hgm.pos.fullmove, c.temperature_start, c.temperature_end, c.temperature_moves);
     if (c.low_visit_threshold > 0 && maxv < c.low_visit_threshold && temp < 0.8) temp = 0.8;
     std::vector<int32_t> visits(R.child_n, R.child_n + k);
-    const int pick = sample_move_index(visits.data(), k, temp, hgm.rng.next());
+    int pick;
+    if (c.arena_mode) {       // arena.py:73-106 (the uniform is drawn only on the sampling branch, as np.random.choice is)
+        const bool sampling = c.arena_temp > 1e-3 && hgm.nstates < c.arena_temp_plies;
+        pick = arena_choose_move(visits.data(), k, c.arena_temp, hgm.nstates, c.arena_temp_plies, sampling ? hgm.rng.next() : 0.0);
+    } else {
+        pick = sample_move_index(visits.data(), k, temp, hgm.rng.next());
+    }
     const Move mv = R.child_mv[pick];
     hgm.search_values.push_back((float)root_q);
     hgm.turns.push_back(hgm.pos.turn == WHITE ? 1 : -1);
@@ -291,7 +308,7 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
     hgm.nstates++;
     sp->stats.plies++;
     // resign (internal.py:507-536)
-    if (resign_update(hgm.resign, root_q, hgm.nstates, c)) {
+    if (!c.arena_mode && resign_update(hgm.resign, root_q, hgm.nstates, c)) {
         const bool white = hgm.pos.turn == WHITE;
         finish_game(sp, slot, true, white ? 1 : 2, true, white ? -1.f : 1.f);
         return;
@@ -303,12 +320,11 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
 }
 
 int run_select(m0_selfplay* sp, int* rows_out) {
-    if (hipMemsetAsync(sp->d.row_counter, 0, 4, sp->stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(sp->d.row_counter, 0, 8, sp->stream) != hipSuccess) return -1;
     if (launch_select(sp->d, sp->tc, sp->stream) != hipSuccess) return -1;
-    int rows = 0;
-    if (hipMemcpyAsync(&rows, sp->d.row_counter, 4, hipMemcpyDeviceToHost, sp->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(sp->rows2, sp->d.row_counter, 8, hipMemcpyDeviceToHost, sp->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(sp->stream) != hipSuccess) return -1;
-    *rows_out = rows;
+    *rows_out = sp->rows2[0];              // network 0's rows; network 1's (arena) start at d.net_row_base
     return 0;
 }
 
@@ -329,18 +345,27 @@ int one_step(m0_selfplay* sp, std::string& err) {
     int rows = 0;
     if (run_select(sp, &rows) != 0) { err = std::string("select failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev1, sp->stream);
-    if (rows > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
+    if (rows > sp->rows_max || sp->rows2[1] > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
     if (rows > 0) {
         if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
         int rc = sp->net->forward(nullptr, sp->d.x0, rows, sp->logits_dev, sp->values_dev,
                                   sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr, sp->stream, err);
         if (rc != M0_OK) return rc;
     }
+    if (sp->rows2[1] > 0) {                 // arena: the other network's leaves, in their own region of the batch
+        if (!sp->net_b) { err = "rows for a second network without one"; return M0_ERR_STATE; }
+        const size_t b = (size_t)sp->d.net_row_base;
+        int rc = sp->net_b->forward(nullptr, sp->d.x0 + b * 64 * 32, sp->rows2[1], sp->logits_dev + b * 4672,
+                                    sp->values_dev + b, nullptr, sp->stream, err);
+        if (rc != M0_OK) return rc;
+        rows += sp->rows2[1];
+    }
     (void)hipEventRecord(sp->ev2, sp->stream);
     if (launch_expand(sp->d, sp->tc, sp->stream) != hipSuccess) { err = "expand launch failed"; return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev3, sp->stream);
     if (sync_games_d2h(sp) != 0) { err = std::string("step failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
     if (sp->net) sp->net->harvest_profile();
+    if (sp->net_b) sp->net_b->harvest_profile();
     float ms_sel = 0, ms_net = 0, ms_exp = 0;
     (void)hipEventElapsedTime(&ms_sel, sp->ev0, sp->ev1);
     (void)hipEventElapsedTime(&ms_net, sp->ev1, sp->ev2);
@@ -383,9 +408,50 @@ int one_step(m0_selfplay* sp, std::string& err) {
 
 }  // namespace
 
+
+// Standard algebraic notation of a legal move (python-chess Board.san semantics: piece letter, minimal
+// disambiguation by file, then rank, then both; 'x'; '=Q'; O-O / O-O-O; '+' / '#') -- PGN output of arena games
+// (arena.py:281-303 writes them with chess.pgn).
+static std::string san_of(const Pos& p, Move m, const Move* legal, int nlegal) {
+    const int from = mv_from(m), to = mv_to(m), promo = mv_promo(m);
+    const int pt = piece_type_at(p, from);
+    std::string s;
+    if (pt == KING && abs((to & 7) - (from & 7)) == 2) {
+        s = (to & 7) > (from & 7) ? "O-O" : "O-O-O";
+    } else {
+        const bool capture = ((p.occ[p.turn ^ 1] >> to) & 1ull) || (pt == PAWN && (from & 7) != (to & 7));
+        if (pt != PAWN) {
+            s += "NBRQK"[pt - 1];
+            bool any = false, same_file = false, same_rank = false;
+            for (int i = 0; i < nlegal; ++i) {
+                const Move o = legal[i];
+                if (o == m || mv_to(o) != to || mv_from(o) == from || piece_type_at(p, mv_from(o)) != pt) continue;
+                any = true;
+                if ((mv_from(o) & 7) == (from & 7)) same_file = true;
+                if ((mv_from(o) >> 3) == (from >> 3)) same_rank = true;
+            }
+            if (any) {
+                if (!same_file) s += (char)('a' + (from & 7));
+                else if (!same_rank) s += (char)('1' + (from >> 3));
+                else { s += (char)('a' + (from & 7)); s += (char)('1' + (from >> 3)); }
+            }
+        } else if (capture) {
+            s += (char)('a' + (from & 7));
+        }
+        if (capture) s += 'x';
+        s += (char)('a' + (to & 7));
+        s += (char)('1' + (to >> 3));
+        if (promo) { s += '='; s += "NBRQ"[promo - 1]; }
+    }
+    Pos q = p;
+    make_move(q, m);
+    if (in_check(q)) s += any_legal(q) ? '+' : '#';
+    return s;
+}
+
 extern "C" {
 
-m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
+static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_selfplay_cfg* cfg) {
     if (!cfg) { m0_set_error("cfg is null"); return nullptr; }
     if (cfg->concurrent_games <= 0 || cfg->inference_batch_size <= 0 || cfg->num_simulations <= 0) {
         m0_set_error("concurrent_games, inference_batch_size and num_simulations must be positive");
@@ -398,6 +464,8 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     fill_tree_cfg(*cfg, sp->tc);
     sp->nethandle = nh;
     sp->net = m0_net_impl(nh);
+    sp->net_b = m0_net_impl(nh_b);
+    sp->cfg.arena_mode = nh_b ? 1 : 0;
     sp->device = nh ? m0_net_device(nh) : 0;
     (void)hipSetDevice(sp->device);
     if (nh) sp->stream = m0_net_stream(nh);
@@ -408,7 +476,8 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     long want = cfg->arena_nodes > 0 ? cfg->arena_nodes : (long)(cfg->num_simulations * 1.3 + 64) * 96;
     if (want < 4096) want = 4096;
     sp->cap = (int)want;
-    sp->rows_max = sp->G * sp->L;
+    sp->rows_max = (sp->G * sp->L + 3) & ~3;
+    const int nreg = nh_b ? 2 : 1;                    // batch regions: one per network
     memset(&sp->stats, 0, sizeof(sp->stats));
     memset(&sp->d, 0, sizeof(sp->d));
     const size_t N = (size_t)sp->G * 2 * sp->cap;
@@ -424,9 +493,10 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     sp->d.hist = dalloc<uint64_t>(sp, (size_t)sp->G * M0_HIST_CAP);
     sp->d.results = dalloc<RootResult>(sp, sp->G);
     sp->d.row_counter = dalloc<int>(sp, 4);
-    sp->d.x0 = dalloc<_Float16>(sp, (size_t)(sp->rows_max + 4) * 64 * 32);
-    sp->logits_dev = dalloc<float>(sp, (size_t)sp->rows_max * 4672);
-    sp->values_dev = dalloc<float>(sp, (size_t)sp->rows_max + 4);
+    sp->d.x0 = dalloc<_Float16>(sp, (size_t)(nreg * sp->rows_max + 4) * 64 * 32);
+    sp->logits_dev = dalloc<float>(sp, (size_t)nreg * sp->rows_max * 4672);
+    sp->values_dev = dalloc<float>(sp, (size_t)nreg * sp->rows_max + 4);
+    sp->d.net_row_base = sp->rows_max;
     if (cfg->ssl_in_forward && sp->net && sp->net->ssl_channels_total() > 0)
         sp->ssl_dev = dalloc<float>(sp, (size_t)sp->rows_max * sp->net->ssl_channels_total() * 64);
     sp->ids_dev = dalloc<int>(sp, sp->G);
@@ -451,9 +521,19 @@ m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) {
     if (sp->net) {
         std::string err;
         if (sp->net->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
+        if (sp->net_b && sp->net_b->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
     }
     (void)hipStreamSynchronize(sp->stream);
     return sp;
+}
+
+m0_selfplay* m0_selfplay_create(m0_net* nh, const m0_selfplay_cfg* cfg) { return selfplay_create_impl(nh, nullptr, cfg); }
+
+m0_selfplay* m0_arena_create(m0_net* net_a, m0_net* net_b, const m0_selfplay_cfg* cfg) {
+    if (!net_a || !net_b) { m0_set_error("m0_arena_create needs two networks"); return nullptr; }
+    if (m0_net_device(net_a) != m0_net_device(net_b)) { m0_set_error("both networks must live on the same HIP device"); return nullptr; }
+    if (cfg && (cfg->ssl_in_forward || cfg->ssl_targets)) { m0_set_error("arena games carry no SSL outputs"); return nullptr; }
+    return selfplay_create_impl(net_a, net_b, cfg);
 }
 
 void m0_selfplay_destroy(m0_selfplay* sp) {
@@ -782,6 +862,48 @@ int m0_rules_probe(const m0_selfplay_cfg* cfg, const char* fen, const char* cons
     *flags = f;
     if (result) *result = game_result(p);
     return M0_OK;
+}
+
+int m0_arena_choose_move(const int32_t* visits, int n, double temp, int ply, int temp_plies, double u) {
+    if (!visits || n <= 0) { m0_set_error("empty visit list"); return M0_ERR_INVALID; }
+    return arena_choose_move(visits, n, temp, ply, temp_plies, u);
+}
+
+int m0_san_legal_fen(const char* fen, uint16_t* moves, char* san, int* nlegal) {
+    if (!fen || !moves || !san || !nlegal) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    Pos p;
+    if (parse_fen(fen, p) != 0) { m0_set_error("bad FEN"); return M0_ERR_INVALID; }
+    Move mv[M0_MAX_MOVES];
+    const int k = gen_legal(p, mv);
+    for (int i = 0; i < k; ++i) {
+        moves[i] = mv[i];
+        const std::string t = san_of(p, mv[i], mv, k);
+        memset(san + 8 * i, 0, 8);
+        memcpy(san + 8 * i, t.c_str(), t.size() < 8 ? t.size() : 7);
+    }
+    *nlegal = k;
+    return M0_OK;
+}
+
+int m0_san_game(const uint16_t* moves, int n, char* out, int cap) {
+    if ((!moves && n > 0) || !out || cap <= 0) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    Pos p;
+    parse_fen("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", p);
+    std::string text;
+    for (int i = 0; i < n; ++i) {
+        Move mv[M0_MAX_MOVES];
+        const int k = gen_legal(p, mv);
+        bool ok = false;
+        for (int j = 0; j < k; ++j) if (mv[j] == moves[i]) ok = true;
+        if (!ok) { m0_set_error("illegal move in game"); return M0_ERR_INVALID; }
+        if (p.turn == WHITE) text += std::to_string(p.fullmove) + ". ";
+        text += san_of(p, moves[i], mv, k);
+        text += ' ';
+        make_move(p, moves[i]);
+    }
+    if ((int)text.size() + 1 > cap) { m0_set_error("output buffer too small"); return M0_ERR_INVALID; }
+    memcpy(out, text.c_str(), text.size() + 1);
+    return (int)text.size();
 }
 
 }  // extern "C"

@@ -51,6 +51,8 @@ struct GameDev {
     uint64_t seed_jitter, seed_noise, seed_dir;
     uint64_t ctr_jitter, ctr_noise, ctr_dir;
     uint64_t evals;           // network evaluations consumed by this game (counted by the engine)
+    int net_id;               // arena: which network evaluates this game's current search (0 / 1); self-play: 0
+    int pad_;
 };
 
 struct Sample {
@@ -95,7 +97,8 @@ struct TreeDev {
     uint16_t* leaf_moves;     // [G][L][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order
     uint64_t* hist;           // [G][M0_HIST_CAP]
     RootResult* results;      // [G]
-    int* row_counter;         // [1]
+    int* row_counter;         // [2]: rows reserved for network 0 / network 1 (arena); row index = net_row_base*net + count
+    int net_row_base;         // first batch row of network 1's region (self-play: unused)
     _Float16* x0;             // network input NHWC [rows][64][32]
     const float* logits;      // [rows][4672]
     const float* values;      // [rows]

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             gd->root_q_from_v = 1;
         }
         int row = 0;
-        if (lane == 0) row = atomicAdd(d.row_counter, 1);
+        if (lane == 0) row = atomicAdd(d.row_counter + gd->net_id, 1) + gd->net_id * d.net_row_base;
         row = __shfl(row, 0);
         const Pos rp = gd->root_pos;
         const int nl = gen_legal_wave(rp, smoves, spseudo, lane);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         }
         int row = -1;
         if (!term) {
-            if (lane == 0) row = atomicAdd(d.row_counter, 1);
+            if (lane == 0) row = atomicAdd(d.row_counter + gd->net_id, 1) + gd->net_id * d.net_row_base;
             row = __shfl(row, 0);
             encode_nhwc(pos, d.x0 + (size_t)row * 64 * 32, lane);
         }

@@ -28,6 +28,7 @@ class SelfplayCfg(C.Structure):
         ("draw_halfmove_cap", c_int), ("draw_material_threshold", c_int), ("draw_stalemate", c_int),
         ("concurrent_games", c_int), ("total_games", c_int), ("first_game_index", c_int), ("arena_nodes", c_int),
         ("seed", c_u64), ("virtual_loss_active", c_int), ("ssl_in_forward", c_int), ("ssl_targets", c_int), ("record_games", c_int),
+        ("arena_mode", c_int), ("arena_temp", c_double), ("arena_temp_plies", c_int),
     ]
 
 
@@ -55,6 +56,10 @@ def _bind():
         return L
     L.m0_selfplay_create.restype = C.c_void_p
     L.m0_selfplay_create.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg)]
+    L.m0_arena_create.restype = C.c_void_p
+    L.m0_arena_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SelfplayCfg)]
+    L.m0_san_legal_fen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(c_int)]
+    L.m0_san_game.argtypes = [C.c_void_p, c_int, C.c_char_p, c_int]
     L.m0_selfplay_destroy.argtypes = [C.c_void_p]
     L.m0_selfplay_destroy.restype = None
     L.m0_selfplay_step.argtypes = [C.c_void_p, c_int]
@@ -79,6 +84,7 @@ def _bind():
     L.m0_temperature_for.restype = c_double
     L.m0_rules_probe.argtypes = [C.POINTER(SelfplayCfg), C.c_char_p, C.POINTER(C.c_char_p), c_int, C.POINTER(c_int),
                                  C.POINTER(C.c_float)]
+    L.m0_arena_choose_move.argtypes = [C.c_void_p, c_int, c_double, c_int, c_int, c_double]
     _bound = True
     return L
 
@@ -199,13 +205,18 @@ class SelfplayEngine:
                 "game_index": r.game_index, "moves": T, "resigned": bool(r.resigned),
                 "resigner": {0: None, 1: "W", 2: "B"}[r.resigner], "draw": bool(r.draw), "result": float(r.result),
                 "avg_policy_entropy": float(r.avg_policy_entropy), "avg_sims": float(r.avg_sims), "secs": float(r.secs),
-                "s": np.ctypeslib.as_array(r.s, shape=(T, 19, 8, 8)).copy(),
-                "pi": np.ctypeslib.as_array(r.pi, shape=(T, 4672)).copy(),
-                "z": np.ctypeslib.as_array(r.z, shape=(T,)).copy(),
-                "legal_mask": np.ctypeslib.as_array(r.legal_mask, shape=(T, 4672)).copy(),
-                "search_values": np.ctypeslib.as_array(r.search_values, shape=(T,)).copy(),
-                "played": [move_to_uci(int(x)) for x in np.ctypeslib.as_array(r.played, shape=(r.total_plies,))],
+                "played": ([move_to_uci(int(x)) for x in np.ctypeslib.as_array(r.played, shape=(r.total_plies,))]
+                           if r.total_plies > 0 else []),
+                "played_raw": (np.ctypeslib.as_array(r.played, shape=(r.total_plies,)).copy()
+                               if r.total_plies > 0 else np.zeros(0, np.uint16)),
             }
+            if r.s and T > 0:                                  # arena records carry only the moves and the result
+                out["s"] = np.ctypeslib.as_array(r.s, shape=(T, 19, 8, 8)).copy()
+                out["pi"] = np.ctypeslib.as_array(r.pi, shape=(T, 4672)).copy()
+                out["legal_mask"] = np.ctypeslib.as_array(r.legal_mask, shape=(T, 4672)).copy()
+            if T > 0:
+                out["z"] = np.ctypeslib.as_array(r.z, shape=(T,)).copy()
+                out["search_values"] = np.ctypeslib.as_array(r.search_values, shape=(T,)).copy()
             if r.ssl:
                 ssl = np.ctypeslib.as_array(r.ssl, shape=(T, 17, 8, 8)).copy()
                 # NPZ field shapes of selfplay/internal.py:475-482: piece [T,13,8,8], the others [T,8,8]
@@ -296,3 +307,46 @@ def ssl_targets_fens(fens, device_index: int = 0) -> dict:
     out = np.empty((n, 17, 8, 8), np.float32)
     _lib.check(L.m0_ssl_targets_fens(int(device_index), arr, n, out.ctypes.data_as(C.c_void_p)), "m0_ssl_targets_fens")
     return {"piece": out[:, :13], "threat": out[:, 13], "pin": out[:, 14], "fork": out[:, 15], "control": out[:, 16]}
+
+
+class ArenaEngine(SelfplayEngine):
+    """Evaluation match engine (m0_arena_create): game i has `backend_a` as White when i is even; step / poll / stats as
+    SelfplayEngine.  Records carry `played`, `result` (White's point of view) and `moves`."""
+
+    def __init__(self, backend_a, backend_b, cfg: SelfplayCfg):
+        self._L = _bind()
+        self.backend = backend_a
+        self.backend_b = backend_b
+        self.cfg = cfg
+        self._h = self._L.m0_arena_create(backend_a.handle, backend_b.handle, C.byref(cfg))
+        if not self._h:
+            raise RuntimeError(f"m0_arena_create failed: {_lib.last_error()}")
+
+
+def arena_choose_move(visits, temp: float, ply: int, temp_plies: int, u: float) -> int:
+    """arena.py:73-106 (host_rules.h::arena_choose_move)."""
+    L = _bind()
+    v = np.ascontiguousarray(visits, dtype=np.int32)
+    return int(L.m0_arena_choose_move(v.ctypes.data_as(C.c_void_p), int(len(v)), float(temp), int(ply), int(temp_plies), float(u)))
+
+
+def san_legal(fen: str):
+    """[(uci, san)] of the legal moves of `fen` in legal_moves order (python-chess Board.san semantics)."""
+    L = _bind()
+    mv = np.zeros(256, np.uint16)
+    san = C.create_string_buffer(256 * 8)
+    n = c_int(0)
+    _lib.check(L.m0_san_legal_fen(fen.encode(), mv.ctypes.data_as(C.c_void_p), san, C.byref(n)), "m0_san_legal_fen")
+    raw = san.raw
+    return [(move_to_uci(int(mv[i])), raw[8 * i: 8 * i + 8].split(b"\0", 1)[0].decode()) for i in range(n.value)]
+
+
+def san_game(moves_raw) -> str:
+    """Movetext '1. e4 e5 2. Nf3 ...' of a game from the start position (moves as in a record's `played_raw`)."""
+    L = _bind()
+    mv = np.ascontiguousarray(moves_raw, dtype=np.uint16)
+    buf = C.create_string_buffer(16 * (len(mv) + 4))
+    rc = L.m0_san_game(mv.ctypes.data_as(C.c_void_p), int(len(mv)), buf, len(buf))
+    if rc < 0:
+        _lib.check(rc, "m0_san_game")
+    return buf.value.decode().strip()

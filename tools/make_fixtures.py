@@ -19,3 +19,18 @@ for fn in sorted(glob.glob(os.path.join(REF, "data/stockfish_games/**/*.json"), 
 with gzip.open(os.path.join(OUT, "stockfish_best_moves.json.gz"), "wt") as f:
     json.dump(out, f, separators=(",", ":"))
 print(len(rows), len(out))
+
+# data/eval_games/*.pgn (125 games written by python-chess) -> tests/golden/eval_games_san.json.gz
+# one entry per game: [[SAN tokens...], result] -- pins SAN generation (m0_san_*) and whole-game replay
+import re
+games = []
+for fn in sorted(glob.glob(os.path.join(REF, "data/eval_games/*.pgn"))):
+    txt = open(fn).read()
+    res = re.search(r'\[Result "([^"]+)"\]', txt).group(1)
+    body = txt.split("\n\n", 1)[1] if "\n\n" in txt else ""
+    body = re.sub(r"\{[^}]*\}", " ", body)
+    toks = [t for t in body.split() if not re.fullmatch(r"\d+\.(\.\.)?", t) and t not in ("1-0", "0-1", "1/2-1/2", "*")]
+    games.append([toks, res])
+with gzip.open(os.path.join(OUT, "eval_games_san.json.gz"), "wt") as f:
+    json.dump(games, f, separators=(",", ":"))
+print(len(games), sum(len(g[0]) for g in games))
