@@ -550,6 +550,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
     constexpr int VROW = 68;                           // halfs per LDS row (64 keys + pad: 136 B, conflict-free b64 reads)
     __shared__ __attribute__((aligned(16))) _Float16 Vt[4][16][VROW];
     __shared__ __attribute__((aligned(16))) _Float16 Bs[4][64][VROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Ms[64][VROW];       // visibility mask as 0/1 (same for every head and board)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, C = a.C;
     const int hgroups = (H + 3) >> 2;
@@ -566,6 +567,13 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
                 *reinterpret_cast<half4s*>(&Bs[hh][q][k4]) = half4s{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
             }
         }
+    }
+    for (int i = tid; i < 64 * 16; i += 256) {                     // 4 keys per item
+        const int q = i >> 4, k4 = (i & 15) * 4;
+        const uint64_t m = a.mask[q] >> k4;
+        typedef _Float16 half4s __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<half4s*>(&Ms[q][k4]) = half4s{(_Float16)(float)(m & 1), (_Float16)(float)((m >> 1) & 1),
+                                                        (_Float16)(float)((m >> 2) & 1), (_Float16)(float)((m >> 3) & 1)};
     }
     __syncthreads();
     for (int it = 0; it < ATT_BOARDS; ++it) {
@@ -617,30 +625,27 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
         float16v st[2];
         st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qfr, zero, 0, 0, 0);
         st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qfr, zero, 0, 0, 0);
-        const uint64_t mrow = a.mask[q];
-        const uint32_t mlo = (uint32_t)mrow, mhi = (uint32_t)(mrow >> 32);
         const _Float16* rb = a.rel_bias ? &Bs[wave][q][0] : nullptr;
+        const _Float16* vm = &Ms[q][0];          // 1 where the mask lets query q see the key, as an fp16 multiplicand
         // scores clamped to [-50,50]: exp needs no max subtraction; masked fill -1e4 underflows to exactly 0
-        float e[2][16];                          // +exp(score) where the mask allows the key, -exp(score) where not
+        float e[2][16];
         float su = 0.f, sm = 0.f;
         static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
             constexpr int kt = decltype(kt_)::value;
-            const uint32_t mw = (kt == 0 ? mlo : mhi) >> (4 * half);       // bit (8 g + j) = key kt*32 + 8 g + 4 half + j
             static_for<0, 4>([&](auto g_) __attribute__((always_inline)) {
                 constexpr int g = decltype(g_)::value;
                 const int key0 = kt * 32 + 8 * g + 4 * half;
                 half4v bias = {0, 0, 0, 0};
                 if (rb) bias = *reinterpret_cast<const half4v*>(rb + key0);
-                const float bb[4] = {(float)bias[0], (float)bias[1], (float)bias[2], (float)bias[3]};
+                const half4v vis = *reinterpret_cast<const half4v*>(vm + key0);
                 static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
                     constexpr int j = decltype(j_)::value;
-                    float d = st[kt][4 * g + j] * isd + bb[j];
+                    float d = st[kt][4 * g + j] * isd + (float)bias[j];
                     d = __builtin_amdgcn_fmed3f(d, -clampv, clampv);
                     const float eu = __builtin_amdgcn_exp2f(d);
-                    const float es = (mw & (1u << (8 * g + j))) ? eu : -eu;
-                    e[kt][4 * g + j] = es;
+                    e[kt][4 * g + j] = eu;
                     su += eu;
-                    sm += fmaxf(es, 0.f);
+                    sm += eu * (float)vis[j];
                 });
             });
         });
@@ -654,10 +659,14 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnArgs a) {
             static_for<0, 2>([&](auto jb_) __attribute__((always_inline)) {
                 constexpr int jb = decltype(jb_)::value;
                 half8 pf;
+                // regs 8jb..8jb+3 = keys kt*32 + 16 jb + 4 half + {0..3}, regs +4..+7 = the same + 8
+                const half4v v0 = *reinterpret_cast<const half4v*>(vm + kt * 32 + 16 * jb + 4 * half);
+                const half4v v1 = *reinterpret_cast<const half4v*>(vm + kt * 32 + 16 * jb + 8 + 4 * half);
                 static_for<0, 8>([&](auto u_) __attribute__((always_inline)) {
                     constexpr int u = decltype(u_)::value;
                     constexpr int r = 8 * jb + u;                          // key = kt*32 + (r&3) + 8*(r>>2) + 4*half
-                    pf[u] = (_Float16)(fabsf(e[kt][r]) * cu + fmaxf(e[kt][r], 0.f) * cm);
+                    const float vis = (float)(u < 4 ? v0[u & 3] : v1[u & 3]);
+                    pf[u] = (_Float16)(e[kt][r] * (vis * cm + cu));
                 });
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt][jb], pf, oacc, 0, 0, 0);
             });
