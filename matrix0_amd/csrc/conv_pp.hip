@@ -286,8 +286,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     };
     if (wn == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the tail's refetches land before the epilogue reuses LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tail refetches / fillers have landed
     if (wn == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
+    // One more barrier, with every wave's vmcnt(0) before it: group 1 reaches its wait only AFTER the barrier that
+    // releases group 0 above, so without this group 0 could stage its output tile while group 1's last DMA pieces are
+    // still on their way into the same LDS bytes.
+    __builtin_amdgcn_s_barrier();
 
 #ifdef PP_NO_EPILOGUE
     asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[0][4]));
