@@ -206,6 +206,36 @@ def test_full_size_configuration_properties():
             b.push(m)
 
 
+def test_full_size_selfplay_is_reproducible():
+    """Same seed, same build -> the same games, bit for bit, at the benchmark network size (64 games, 800 simulations,
+    one searched ply): any race in the MFMA kernels' LDS / DMA choreography shows up here as a different visit count."""
+    import bench
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.SELFPLAY_CFG.items()}
+    cfgd["selfplay"] = dict(cfgd["selfplay"], max_game_len=1)
+    be = M0Backend.from_state_dict(bench.R24_320, net_ref.random_state_dict(bench.R24_320, seed=0))
+    runs = []
+    for _ in range(2):
+        cfg = eng.selfplay_cfg_from_dict(cfgd, concurrent_games=64, total_games=64, leaves_per_step=16,
+                                         virtual_loss_active=True, record_games=True)
+        e = eng.SelfplayEngine(be, cfg)
+        games = {}
+        for _ in range(200):
+            e.step(10)
+            while (r := e.poll()) is not None:
+                games[r["game_index"]] = r
+            if not e.running():
+                break
+        e.close()
+        assert len(games) == 64
+        runs.append(games)
+    for i in range(64):
+        a, b = runs[0][i], runs[1][i]
+        assert a["played"] == b["played"], i
+        assert np.array_equal(a["pi"], b["pi"]) and np.array_equal(a["search_values"], b["search_values"]), i
+
+
 def test_baseline_config0_one_game_64_sims_full_size_net():
     """BASELINE configs[0] as a parity case: 1 self-play game, 64 sims/move, random-init R24-320 (the reference's
     CPU-runnable case), here on the GPU; the game is replayed through the oracle's rules and encoder."""
