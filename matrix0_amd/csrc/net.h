@@ -21,7 +21,6 @@ struct PackedGemm {
     float* bias = nullptr;   // [N] or null
     int taps = 1, Cin = 0, N = 0;
     bool pp = false;         // 3x3 big tile in conv_pp_kernel's layout [chunk*9+tap][N/320][k half][320][32]
-    bool n160 = false;       // 1x1 in conv1x1_kernel's layout [k step of 32][N/160][160][32]
 };
 
 struct NormParams {
@@ -135,7 +134,7 @@ private:
     const HostTensor* get(const std::string& k, std::string& err);
     int pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads = 0,
-                  int qkv_heads_pad = 0, bool n160 = false);
+                  int qkv_heads_pad = 0);
     int upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err);
     float* upload_f32(const std::vector<float>& v);
     void* dalloc(size_t bytes, bool ws);

@@ -100,7 +100,7 @@ const HostTensor* Net::get(const std::string& k, std::string& err) {
 }
 
 int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
-                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads, int qkv_heads_pad, bool n160) {
+                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads, int qkv_heads_pad) {
     const HostTensor* w = get(wkey, err);
     if (!w) return M0_ERR_INVALID;
     size_t expect = (size_t)N_real * Cin_real * taps;
@@ -110,7 +110,6 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     const int nchunk = Cin_pad / KC;
     const bool pp = KC == 64 && taps == 9;       // 3x3 big tile: conv_pp_kernel's half-tile layout
     const int nblk = N_pad / 320;
-    const bool n160c = n160 && taps == 1 && KC == 64 && N_pad % 160 == 0 && k_perm_ch == 0;   // plain-epilogue 1x1 convs
     std::vector<_Float16> p((size_t)taps * Cin_pad * N_pad, (_Float16)0.f);
     for (int nr = 0; nr < N_real; ++nr)
         for (int k = 0; k < Cin_real; ++k)
@@ -127,12 +126,6 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
                     kk = sq * k_perm_ch + c;
                 }
                 int chunk = kk / KC, kc = kk % KC;
-                if (n160c) {    // conv1x1_kernel: K steps of 32, N blocks of 160, 64-byte rows, chunk ^ (row>>2)&3
-                    const int st = kk >> 5, k32 = kk & 31, by = n / 160, nl = n % 160;
-                    const int kx = (((k32 >> 3) ^ ((nl >> 2) & 3)) << 3) | (k32 & 7);
-                    p[((((size_t)st * (N_pad / 160) + by) * 160 + nl) * 32) + kx] = (_Float16)v;
-                    continue;
-                }
                 if (pp) {       // conv_pp_kernel: half-K-tiles of 320 x 32 k, 64-byte rows, chunk ^ (row>>2)&3
                     const int kt = chunk * 9 + t, by = n / 320, nl = n % 320, h = kc >> 5, k32 = kc & 31;
                     const int kx = (((k32 >> 3) ^ ((nl >> 2) & 3)) << 3) | (k32 & 7);
@@ -146,7 +139,7 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     g.w = (_Float16*)dalloc(p.size() * 2, false);
     if (!g.w) { err = "hipMalloc failed"; return M0_ERR_HIP; }
     (void)hipMemcpy(g.w, p.data(), p.size() * 2, hipMemcpyHostToDevice);
-    g.taps = taps; g.Cin = Cin_pad; g.N = N_pad; g.pp = pp; g.n160 = n160c;
+    g.taps = taps; g.Cin = Cin_pad; g.N = N_pad; g.pp = pp;
     g.bias = nullptr;
     if (!bkey.empty()) {
         const HostTensor* b = get(bkey, err);
@@ -194,7 +187,7 @@ int Net::finalize(std::string& err) {
             for (int n = 0; n < 64; ++n) t[(size_t)n * P + c] = pe->data[(size_t)c * 64 + n];
         posenc_ = upload_f32(t);
         if (cfg_.piece_square_tables) {
-            TRY(pack_gemm(pst_, "chess_features.pst_conv.weight", "", 1, C, P, C, P, 0, err, 0, 0, true));
+            TRY(pack_gemm(pst_, "chess_features.pst_conv.weight", "", 1, C, P, C, P, 0, err));
             TRY(upload_norm(pst_n_, "chess_features.pst_norm", C, P, err));
         }
         TRY(pack_gemm(inter_, "chess_features.interaction_conv.weight", "", 9, C, P, C, P, 0, err));
@@ -241,8 +234,8 @@ int Net::finalize(std::string& err) {
                 }
                 continue;
             }
-            TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, P, 3 * C, 3 * P, 0, err, P != C ? cfg_.attention_heads : 0, P / 16, true));
-            TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, P, C, P, 0, err, 0, 0, true));
+            TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, P, 3 * C, 3 * P, 0, err, P != C ? cfg_.attention_heads : 0, P / 16));
+            TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, P, C, P, 0, err));
             TRY(upload_norm(a.ln, p + ".norm", C, P, err));
             if (cfg_.attention_relbias) {
                 const HostTensor* rb = get(p + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
@@ -392,7 +385,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     a.gn_beta = out_norm ? out_norm->beta : nullptr;
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
-    a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale; a.w_pp = g.n160 ? 2 : (g.pp ? 1 : 0);
+    a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale; a.w_pp = g.pp ? 1 : 0;
     const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {

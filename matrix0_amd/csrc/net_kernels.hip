@@ -230,7 +230,6 @@ static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
 hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st);              // conv_pp.hip
-hipError_t launch_conv1x1(const GemmArgs& a, hipStream_t st);              // conv1x1.hip
 
 int conv_gemm_tile_n(int Cin, int Npad) {
     return (Npad % 320 == 0 && Cin % 64 == 0) ? 320 : 32;
@@ -247,7 +246,7 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
         if (big) return a.w_pp ? launch_conv_pp(a, st) : hipErrorInvalidValue;
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
     } else if (taps == 1) {
-        if (big) return a.w_pp == 2 ? launch_conv1x1(a, st) : (a.w_pp ? hipErrorInvalidValue : launch_conv_big(a, 1, st));
+        if (big) return a.w_pp ? hipErrorInvalidValue : launch_conv_big(a, 1, st);
         return launch_conv_gemm_t<1, 1, 1, 32>(a, st);
     }
     return hipErrorInvalidValue;
