@@ -52,6 +52,14 @@ def lib():
         raise EngineLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). matrix0_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libm0engine.so is linked against the
+    # system one with the same SONAME.  If torch comes first the loader hands libm0engine the copy already resident;
+    # the other way round the process ends up with two runtimes and the second to touch the device finds none
+    # (observed: build() then smoke() in one interpreter).  torch is a dependency anyway (checkpoints, distributed).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     L.m0_last_error.restype = C.c_char_p
     L.m0_version.restype = C.c_char_p
