@@ -1,0 +1,411 @@
+// attn_block_kernel: one whole ChessAttention block of the tower (resnet.py:133-181: qkv 1x1 -> per-head
+// scores / softmax / PV -> proj 1x1 -> residual add -> LayerNorm) plus the pre-activation GroupNorm of the residual
+// block that follows, in ONE kernel for the 320-channel trunk.
+//
+// Why: as four kernels (qkv GEMM, attn_core, proj GEMM, ew_board) the block moved 2.5 GB through HBM per launch at
+// 4096 boards -- the [B][64][960] qkv tensor alone is written and read back (1 GB) -- and took 856 us against 310 us of
+// traffic; here only the trunk is read (168 MB) and the outputs are written.
+//
+// Workgroup = 2 boards = 128 token rows, 8 waves.  The boards' trunk rows X [128][320] stay in LDS for the whole
+// kernel (A operand of every qkv GEMM and the residual at the end).  The 20 heads are processed in 10 groups of 2:
+//   1. qkv GEMM of the group  [128 x 320] x [320 x 96]   (96 = q,k,v of 2 heads; 5 weight pieces of K = 64)
+//      -> Q, K as [head][token][16] and V transposed [unit][16][token] in LDS (fp16, as the split path's qkv tensor);
+//   2. attention of the 4 (board, head) units, one per wave pair (a wave owns 32 queries): S^T = K Q^T and
+//      O^T = V^T P^T on MFMA 32x32x16 exactly as attn_core_kernel; the relative-position bias of the wave's
+//      (head, query half) arrives in registers from a table pre-arranged in accumulator order; O overwrites Q;
+//   3. proj GEMM accumulate  out[128 x 320] += O[128 x 32] x Wproj[32 x 320]  (2 weight pieces) into 80 accumulator
+//      registers per lane that live across all groups (a wave owns 16 tokens x all 320 channels, so LayerNorm needs no
+//      cross-wave reduction and GroupNorm group j is accumulator tile j).
+// All GEMM tiles are MFMA 16x16x32 in the "swapped" orientation (A = weights, B = activations): the accumulator then
+// holds 4 consecutive channels of one token per lane = one 8-byte LDS write.
+// The weights of the whole block are one stream of 70 pieces of 12 KB (host-packed in LDS image order, net.hip)
+// through a 4-slot ring filled three pieces ahead by global_load_lds (two DMA instructions per wave and piece, so every
+// wave's vmcnt bookkeeping is identical); one barrier per piece.
+#include "kernel_common.h"
+#include "conv_epilogue.h"
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int AB_PIECE = 12288;
+constexpr int AB_PIECES_PER_GROUP = 7;
+constexpr int AB_GROUPS = 10;
+constexpr int AB_X = 0;                                   // [128][640 B], 16-byte chunk ^ (row>>1)&7 within 128 B
+constexpr int AB_QK = 81920;                              // Q [2][128][16] | K [2][128][16]   (O overlays Q)
+constexpr int AB_VT = AB_QK + 16384;                      // [4 units][16][68]
+constexpr int AB_VROW = 68;
+constexpr int AB_RING = AB_VT + 4 * 16 * AB_VROW * 2;     // 107008
+constexpr int AB_PAR = AB_RING + 4 * AB_PIECE;            // 156160: LayerNorm gamma, beta, next GroupNorm gamma, beta [4][320] f32
+constexpr int AB_LDS = AB_PAR + 4 * 320 * 4;              // 161280
+}
+
+__device__ __forceinline__ void ab_dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int CTRL>
+__device__ __forceinline__ float ab_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (every lane gets the total; fixed order)
+__device__ __forceinline__ float ab_row_sum(float v) {
+    v += ab_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += ab_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += ab_dpp<0x141>(v);     // row_half_mirror
+    v += ab_dpp<0x140>(v);     // row_mirror
+    return v;
+}
+
+#ifndef AB_DBG
+#define AB_DBG 0
+#endif
+#define AB_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define AB_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int ACT>
+__global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4, r31 = lane & 31, half = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const size_t b0 = (size_t)blockIdx.x * 2;
+    const char* xg = reinterpret_cast<const char*>(a.x) + b0 * 64 * 640;
+
+    // ---- prologue: the two boards' rows and the first three weight pieces
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+        const int idx = w * 10 + n;
+        const int q = idx * 64 + lane;
+        const int row = q / 40, pos = q - row * 40;
+        const int src = (pos & ~7) | ((pos ^ (row >> 1)) & 7);
+        ab_dma16(xg + row * 640 + src * 16, smem + AB_X + idx * 1024);
+    }
+    // a piece is 12 x 1 KB: every wave issues one full 16-byte DMA and one with its upper 32 lanes masked off (1.5 KB per
+    // wave), so the count of outstanding vector-memory operations is the same in all 8 waves.  (global_load_lds_dwordx3
+    // would give 16 x 768 B, but on gfx950 it places lane i's 12 bytes at base + 16 i.)
+    const char* wsrc = reinterpret_cast<const char*>(a.wpack) + w * 1536 + lane * 16;
+    char* const ring_w = smem + AB_RING + w * 1536;
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const char* s = wsrc + (size_t)t * AB_PIECE;
+        char* d = ring_w + (t & 3) * AB_PIECE;
+        ab_dma16(s, d);
+        if (lane < 32) ab_dma16(s + 1024, d + 1024);
+    };
+    issue(0); issue(1); issue(2);
+    if (tid < 320) {
+        float* par = reinterpret_cast<float*>(smem + AB_PAR);
+        par[tid] = a.ln_g[tid]; par[320 + tid] = a.ln_b[tid];
+        par[640 + tid] = a.y2 ? a.gn2_gamma[tid] : 0.f; par[960 + tid] = a.y2 ? a.gn2_beta[tid] : 0.f;
+    }
+
+#if AB_DBG == 3
+    AB_WAIT(0);
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = tid; i < 3 * AB_PIECE / 4; i += 512)
+            reinterpret_cast<uint32_t*>(a.y)[i] = reinterpret_cast<const uint32_t*>(smem + AB_RING)[i];
+    return;
+#endif
+    // ---- attention role of this wave: unit = (board, head-in-group), query half
+    const int au = w >> 1, aboard = au >> 1, ahl = au & 1, aqt = w & 1;
+    const int aq = aqt * 32 + r31;
+    // visibility of key (kt, r) from query aq as an fp16 multiplicand, accumulator order: key = kt*32 + 8(r>>2) + 4 half + (r&3)
+    half2v visr[16];
+    {
+        const uint64_t m = a.mask[aq];
+        static_for<0, 16>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_)::value;
+            constexpr int kt = i >> 3, r = (2 * i) & 15;
+            const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            visr[i] = half2v{(_Float16)(float)((m >> key) & 1), (_Float16)(float)((m >> (key + 1)) & 1)};
+        });
+    }
+    float wm_, wu_;   // output weights of the masked / unmasked branch (resnet.py:154-174)
+    if (a.mix > 0.f && a.mix < 1.f) { wm_ = 1.f - a.mix; wu_ = 1.f - (1.f - a.mix); }
+    else if (a.mix >= 1.f) { wm_ = 1.f; wu_ = 0.f; }
+    else { wm_ = 0.f; wu_ = 1.f; }
+    const float isd = a.inv_sqrt_d * 1.44269504088896f;
+    const float clampv = 50.f * 1.44269504088896f;
+
+    // ---- per-lane LDS offsets
+    const int xrow0 = 32 * wm + l15;
+    const int xsw = (xrow0 >> 1) & 7;
+    const int xe0 = ((lq ^ xsw) & 7) * 16, xe1 = (((4 + lq) ^ xsw) & 7) * 16;
+    const char* xb0 = smem + AB_X + xrow0 * 640;
+    const char* xb1 = xb0 + 16 * 640;
+    const int wsw = (l15 >> 1) & 7;
+    const int wq0 = (3 * wn * 16 + l15) * 128 + ((lq ^ wsw) & 7) * 16;            // qkv piece, kk = 0
+    const int wq1 = (3 * wn * 16 + l15) * 128 + (((4 + lq) ^ wsw) & 7) * 16;      // kk = 1
+    const int wpo = l15 * 64 + ((lq ^ (l15 >> 2)) & 3) * 16;                      // proj piece
+    const char* ring = smem + AB_RING;
+
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4v oc[20];
+    static_for<0, 20>([&](auto j_) __attribute__((always_inline)) { oc[decltype(j_)::value] = zero4; });
+
+#pragma unroll 1
+    for (int g = 0; g < (AB_DBG == 1 ? 0 : AB_GROUPS); ++g) {
+        const int t0 = g * AB_PIECES_PER_GROUP;
+        float4v qa[2][3];
+        static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
+            static_for<0, 3>([&](auto j_) __attribute__((always_inline)) { qa[decltype(i_)::value][decltype(j_)::value] = zero4; });
+        });
+        half8 bias8[4];
+        // ---- 1. qkv GEMM of the group: 5 pieces of K = 64
+        static_for<0, 5>([&](auto p_) __attribute__((always_inline)) {
+            constexpr int p = decltype(p_)::value;
+            if constexpr (p < 3) AB_WAIT(4); else AB_WAIT(8);
+            __builtin_amdgcn_s_barrier();
+            issue(t0 + p + 3);
+            if constexpr (p == 2) {
+                // relative-position bias of (head, query half) in accumulator order: 64 B per lane
+                const half8* bp = reinterpret_cast<const half8*>(a.bias) +
+                                  ((size_t)((2 * g + ahl) * 2 + aqt) * 64 + lane) * 4;
+                // (inline asm: at the first use of an ordinary load's result hipcc waits vmcnt(0), which would drain the
+                // weight pieces in flight; the counted wait before the scores below covers these four)
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                             : "=&v"(bias8[0]), "=&v"(bias8[1]), "=&v"(bias8[2]), "=&v"(bias8[3]) : "v"(bp) : "memory");
+            }
+            const char* slot = ring + ((t0 + p) & 3) * AB_PIECE;
+            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kk_)::value;
+                constexpr int ks = 2 * p + kk;
+                const int xo = 128 * (ks >> 1) + ((ks & 1) ? xe1 : xe0);
+                const half8 xf0 = *reinterpret_cast<const half8*>(xb0 + xo);
+                const half8 xf1 = *reinterpret_cast<const half8*>(xb1 + xo);
+                const char* wb = slot + (kk ? wq1 : wq0);
+                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_)::value;
+                    const half8 wf = *reinterpret_cast<const half8*>(wb + j * 2048);
+                    qa[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf0, qa[0][j], 0, 0, 0);
+                    qa[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf1, qa[1][j], 0, 0, 0);
+                });
+            });
+        });
+        // ---- stage q, k (token-major) and v (transposed) as fp16
+        static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
+            static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
+                const int J = 3 * wn + j, type = J >> 1, hl = J & 1;          // wave-uniform
+                const int token = 32 * wm + 16 * i + l15;
+                const half4v h = {(_Float16)qa[i][j][0], (_Float16)qa[i][j][1], (_Float16)qa[i][j][2], (_Float16)qa[i][j][3]};
+                if (type < 2) {
+                    *reinterpret_cast<half4v*>(smem + AB_QK + type * 8192 + hl * 4096 + token * 32 + lq * 8) = h;
+                } else {
+                    const int unit = (token >> 6) * 2 + hl, sq = token & 63;
+                    _Float16* vt = reinterpret_cast<_Float16*>(smem + AB_VT) + (unit * 16 + 4 * lq) * AB_VROW + sq;
+                    vt[0] = h[0]; vt[AB_VROW] = h[1]; vt[2 * AB_VROW] = h[2]; vt[3 * AB_VROW] = h[3];
+                }
+            });
+        });
+        AB_LGKM0();                                           // raw barrier: __syncthreads() would drain the weight DMA
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- 2. attention of this wave's (board, head, query half)
+        if (AB_DBG != 2) {
+            const char* Kb = smem + AB_QK + 8192 + ahl * 4096 + aboard * 64 * 32;
+            const half8 kf0 = *reinterpret_cast<const half8*>(Kb + r31 * 32 + 16 * half);
+            const half8 kf1 = *reinterpret_cast<const half8*>(Kb + (32 + r31) * 32 + 16 * half);
+            char* Qp = smem + AB_QK + ahl * 4096 + (aboard * 64 + aq) * 32 + 16 * half;      // also where O goes
+            const half8 qfr = *reinterpret_cast<const half8*>(Qp);
+            half8 vf[2][2];
+            {
+                const _Float16* vrow = reinterpret_cast<const _Float16*>(smem + AB_VT) + (au * 16 + l15) * AB_VROW;
+                static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+                    static_for<0, 2>([&](auto jb_) __attribute__((always_inline)) {
+                        constexpr int kt = decltype(kt_)::value, jb = decltype(jb_)::value;
+                        const half4v lo = *reinterpret_cast<const half4v*>(vrow + kt * 32 + 16 * jb + 4 * half);
+                        const half4v hi = *reinterpret_cast<const half4v*>(vrow + kt * 32 + 16 * jb + 8 + 4 * half);
+                        vf[kt][jb] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    });
+                });
+            }
+            float16v st[2];
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qfr, zero16, 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qfr, zero16, 0, 0, 0);
+            // the bias (older than the two pieces issued after it); the operands tie the registers to this point
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(bias8[0]), "+v"(bias8[1]), "+v"(bias8[2]), "+v"(bias8[3]) :: "memory");
+            float e[2][16];
+            float su = 0.f, sm = 0.f;
+            static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int kt = decltype(kt_)::value, r = decltype(r_)::value;
+                    constexpr int bi = kt * 16 + r;
+                    float d = st[kt][r] * isd + (float)bias8[bi >> 3][bi & 7];
+                    d = __builtin_amdgcn_fmed3f(d, -clampv, clampv);
+                    const float eu = __builtin_amdgcn_exp2f(d);
+                    e[kt][r] = eu;
+                    su += eu;
+                    sm += eu * (float)visr[bi >> 1][bi & 1];
+                });
+            });
+            su += __shfl_xor(su, 32);
+            sm += __shfl_xor(sm, 32);
+            const float cu = wu_ / su, cm = wm_ / sm;
+            float16v oacc = zero16;
+            static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
+                static_for<0, 2>([&](auto jb_) __attribute__((always_inline)) {
+                    constexpr int kt = decltype(kt_)::value, jb = decltype(jb_)::value;
+                    half8 pf;
+                    static_for<0, 8>([&](auto u_) __attribute__((always_inline)) {
+                        constexpr int u = decltype(u_)::value;
+                        constexpr int r = 8 * jb + u, bi = kt * 16 + r;
+                        const float vis = (float)visr[bi >> 1][bi & 1];
+                        pf[u] = (_Float16)(e[kt][r] * (vis * cm + cu));
+                    });
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt][jb], pf, oacc, 0, 0, 0);
+                });
+            });
+            // O^T: lane = query, regs 0..7 = head dims (r&3) + 8*(r>>2) + 4*half -> 16 contiguous bytes after one exchange
+            union { half2v h2[2]; uint32_t u[2]; } lo4, hi4, rcv;
+            lo4.h2[0] = half2v{(_Float16)oacc[0], (_Float16)oacc[1]}; lo4.h2[1] = half2v{(_Float16)oacc[2], (_Float16)oacc[3]};
+            hi4.h2[0] = half2v{(_Float16)oacc[4], (_Float16)oacc[5]}; hi4.h2[1] = half2v{(_Float16)oacc[6], (_Float16)oacc[7]};
+            rcv.u[0] = __shfl_xor(half ? lo4.u[0] : hi4.u[0], 32);
+            rcv.u[1] = __shfl_xor(half ? lo4.u[1] : hi4.u[1], 32);
+            typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+            uint4v ov;
+            if (half == 0) ov = uint4v{lo4.u[0], lo4.u[1], rcv.u[0], rcv.u[1]};
+            else ov = uint4v{rcv.u[0], rcv.u[1], hi4.u[0], hi4.u[1]};
+            // (inline asm: before an ordinary LDS store hipcc waits for every LDS-DMA in flight, vmcnt(0))
+            asm volatile("ds_write_b128 %0, %1" :: "v"((uint32_t)(uintptr_t)Qp), "v"(ov) : "memory");
+        }
+        // ---- 3. proj accumulate: two pieces of 160 output channels
+        half8 of;
+        static_for<0, 2>([&](auto hh_) __attribute__((always_inline)) {
+            constexpr int hh = decltype(hh_)::value;
+            if constexpr (hh == 1) AB_WAIT(4);
+            else AB_LGKM0();                                  // this wave's O rows are in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(t0 + 5 + hh + 3);
+            if constexpr (hh == 0)
+                of = *reinterpret_cast<const half8*>(smem + AB_QK + (lq >> 1) * 4096 + (16 * w + l15) * 32 + (lq & 1) * 16);
+            const char* pb = ring + ((t0 + 5 + hh) & 3) * AB_PIECE + wpo;
+            static_for<0, 10>([&](auto jj_) __attribute__((always_inline)) {
+                constexpr int jj = decltype(jj_)::value;
+                const half8 wf = *reinterpret_cast<const half8*>(pb + jj * 1024);
+                oc[10 * hh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, of, oc[10 * hh + jj], 0, 0, 0);
+            });
+        });
+    }
+    // every wave's DMA (the three pad pieces included) has landed and every wave has left the ring before it is reused
+    AB_WAIT(0);
+    __syncthreads();
+
+    // ---- epilogue: residual + LayerNorm (per token: the wave holds all 320 channels of its 16 tokens)
+    const int token = 16 * w + l15;
+    const int tsw = (token >> 1) & 7;
+    char* xrow = smem + AB_X + token * 640 + (lq & 1) * 8;
+    float s1 = 0.f, s2 = 0.f;
+    static_for<0, 20>([&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        const int chunk = 2 * j + (lq >> 1);
+        const int pos = (chunk & ~7) | ((chunk ^ tsw) & 7);
+        const half4v xv = *reinterpret_cast<const half4v*>(xrow + pos * 16);
+        static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const float v = oc[j][r] + (float)xv[r];
+            oc[j][r] = v;
+            s1 += v; s2 += v * v;
+        });
+    });
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float cnt = (float)a.ln_count;
+    const float mean = s1 / cnt;
+    float var = s2 / cnt - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + 1e-5f);
+    const float* par = reinterpret_cast<const float*>(smem + AB_PAR);
+    float2* scr = reinterpret_cast<float2*>(smem + AB_RING);            // [8 waves][20][4] GroupNorm partials
+    float2* tot = scr + 8 * 20 * 4;                                     // [2 boards][20] (mean, rstd)
+    static_for<0, 20>([&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        const float4 gm = *reinterpret_cast<const float4*>(par + 16 * j + 4 * lq);
+        const float4 bt = *reinterpret_cast<const float4*>(par + 320 + 16 * j + 4 * lq);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+        float p1 = 0.f, p2 = 0.f;
+        half4v h;
+        static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const float y = (oc[j][r] - mean) * rstd * gmv[r] + btv[r];
+            p1 += y; p2 += y * y;
+            h[r] = (_Float16)y;
+        });
+        const int chunk = 2 * j + (lq >> 1);
+        const int pos = (chunk & ~7) | ((chunk ^ tsw) & 7);
+        *reinterpret_cast<half4v*>(xrow + pos * 16) = h;                // over this lane's own x values
+        p1 = ab_row_sum(p1); p2 = ab_row_sum(p2);
+        if (l15 == 0) scr[(w * 20 + j) * 4 + lq] = make_float2(p1, p2);
+    });
+    // the wave's 16 rows are contiguous in the output: linear 16-byte reads of the LDS image, swizzle undone on the way
+    auto flush = [&](_Float16* outp) __attribute__((always_inline)) {
+        char* og = reinterpret_cast<char*>(outp) + (b0 * 64 + 16 * w) * 640;
+#pragma unroll
+        for (int n = 0; n < 10; ++n) {
+            const int q = n * 64 + lane;
+            const int rl = q / 40, pos = q - rl * 40;
+            const int grow = 16 * w + rl;
+            const int src = (pos & ~7) | ((pos ^ (grow >> 1)) & 7);
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + AB_X + grow * 640 + pos * 16);
+            *reinterpret_cast<uint4*>(og + rl * 640 + src * 16) = v;
+        }
+    };
+    flush(a.y);
+    if (a.y2 == nullptr) return;
+    // ---- second output: act(GroupNorm16(y)) for the next residual block (statistics per board and 16-channel group)
+    __syncthreads();
+    if (tid < 40) {
+        const int bd = tid / 20, j = tid - bd * 20;
+        float s = 0.f, ss = 0.f;
+        for (int ww = 0; ww < 4; ++ww)
+            for (int q = 0; q < 4; ++q) { const float2 v = scr[((bd * 4 + ww) * 20 + j) * 4 + q]; s += v.x; ss += v.y; }
+        const float mu = s * (1.f / 1024.f);
+        float vr = ss * (1.f / 1024.f) - mu * mu;
+        vr = vr > 0.f ? vr : 0.f;
+        tot[tid] = make_float2(mu, rsqrtf(vr + 1e-5f));
+    }
+    __syncthreads();
+    static_for<0, 20>([&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        const float2 mr = tot[(w >> 2) * 20 + j];
+        const float4 gm = *reinterpret_cast<const float4*>(par + 640 + 16 * j + 4 * lq);
+        const float4 bt = *reinterpret_cast<const float4*>(par + 960 + 16 * j + 4 * lq);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+        const int chunk = 2 * j + (lq >> 1);
+        const int pos = (chunk & ~7) | ((chunk ^ tsw) & 7);
+        half4v h = *reinterpret_cast<const half4v*>(xrow + pos * 16);
+        static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_)::value;
+            const float sc = gmv[r] * mr.y;
+            h[r] = (_Float16)act_fast<ACT>((float)h[r] * sc + (btv[r] - mr.x * sc));
+        });
+        *reinterpret_cast<half4v*>(xrow + pos * 16) = h;
+    });
+    flush(a.y2);
+}
+
+hipError_t launch_attn_block(const AttnBlockArgs& a, hipStream_t st) {
+    if (a.B <= 0 || a.B % 2 != 0 || a.ln_count <= 0 || a.ln_count > 320) return hipErrorInvalidValue;
+    if (a.y2 != nullptr && a.act != ACT_SILU && a.act != ACT_RELU) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_SILU>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_RELU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(a.B / 2));
+    if (a.act == ACT_RELU) hipLaunchKernelGGL(attn_block_kernel<ACT_RELU>, grid, dim3(512), AB_LDS, st, a);
+    else hipLaunchKernelGGL(attn_block_kernel<ACT_SILU>, grid, dim3(512), AB_LDS, st, a);
+    return hipGetLastError();
+}
+
+size_t attn_block_pack_bytes() { return (size_t)(AB_GROUPS * AB_PIECES_PER_GROUP + 3) * AB_PIECE; }

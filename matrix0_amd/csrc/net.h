@@ -39,6 +39,8 @@ struct AttnW {
     PackedGemm qkv, proj;
     NormParams ln;
     float* rel_bias = nullptr;
+    void* blk_w = nullptr;         // attn_block_kernel: qkv + proj weight pieces (320-channel trunk only)
+    _Float16* blk_bias = nullptr;  // rel_bias * log2(e) in accumulator order, fp16
 };
 
 struct TowerLayer {
@@ -135,6 +137,7 @@ private:
     int pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads = 0,
                   int qkv_heads_pad = 0);
+    int pack_attn_block(AttnW& a, const std::string& prefix, std::string& err);
     int upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err);
     float* upload_f32(const std::vector<float>& v);
     void* dalloc(size_t bytes, bool ws);

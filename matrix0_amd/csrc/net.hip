@@ -153,6 +153,66 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     return M0_OK;
 }
 
+// attn_block_kernel operands (attn_block.hip): the block's qkv and proj weights as one stream of 12 KB pieces in LDS
+// image order -- per group g of two heads: five pieces [96 cols = q,k,v x 2 heads x 16][64 k] (128-byte rows, 16-byte
+// chunk ^ (col>>1)&7) and two pieces [160 output channels][32 k = 2 heads x 16] (64-byte rows, chunk ^ (ch>>2)&3, padded
+// to 12 KB) -- and the relative-position bias per (head, query half, lane) in MFMA accumulator order.
+int Net::pack_attn_block(AttnW& a, const std::string& prefix, std::string& err) {
+    const HostTensor* wq = get(prefix + ".qkv.weight", err); if (!wq) return M0_ERR_INVALID;
+    const HostTensor* wp = get(prefix + ".proj.weight", err); if (!wp) return M0_ERR_INVALID;
+    const int Cr = C_, Hr = cfg_.attention_heads;
+    if (Cp_ != 320 || Cr != Hr * 16 || wq->data.size() != (size_t)3 * Cr * Cr || wp->data.size() != (size_t)Cr * Cr) {
+        err = "shape mismatch for " + prefix; return M0_ERR_INVALID;
+    }
+    std::vector<_Float16> buf(attn_block_pack_bytes() / 2, (_Float16)0.f);
+    auto qkv_w = [&](int type, int h, int d, int k) -> float {
+        return (h < Hr && k < Cr) ? wq->data[(size_t)((type * Hr + h) * 16 + d) * Cr + k] : 0.f;
+    };
+    auto proj_w = [&](int oc, int h, int d) -> float {
+        return (oc < Cr && h < Hr) ? wp->data[(size_t)oc * Cr + h * 16 + d] : 0.f;
+    };
+    for (int g = 0; g < 10; ++g) {
+        for (int pc = 0; pc < 5; ++pc) {
+            const size_t base = (size_t)(g * 7 + pc) * 6144;
+            for (int col = 0; col < 96; ++col) {
+                const int J = col >> 4, type = J >> 1, hl = J & 1, d = col & 15;
+                for (int k = 0; k < 64; ++k) {
+                    const int pos = (k >> 3) ^ ((col >> 1) & 7);
+                    buf[base + (size_t)col * 64 + pos * 8 + (k & 7)] = (_Float16)qkv_w(type, 2 * g + hl, d, 64 * pc + k);
+                }
+            }
+        }
+        for (int hh = 0; hh < 2; ++hh) {
+            const size_t base = (size_t)(g * 7 + 5 + hh) * 6144;
+            for (int cl = 0; cl < 160; ++cl)
+                for (int k = 0; k < 32; ++k) {
+                    const int pos = (k >> 3) ^ ((cl >> 2) & 3);
+                    buf[base + (size_t)cl * 32 + pos * 8 + (k & 7)] = (_Float16)proj_w(160 * hh + cl, 2 * g + (k >> 4), k & 15);
+                }
+        }
+    }
+    a.blk_w = dalloc(buf.size() * 2, false);
+    if (!a.blk_w) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+    (void)hipMemcpy(a.blk_w, buf.data(), buf.size() * 2, hipMemcpyHostToDevice);
+    std::vector<_Float16> bb((size_t)20 * 2 * 64 * 32, (_Float16)0.f);
+    if (cfg_.attention_relbias) {
+        const HostTensor* rb = get(prefix + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
+        for (int h = 0; h < Hr; ++h)
+            for (int qt = 0; qt < 2; ++qt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 32; ++e) {
+                        const int kt = e >> 4, r = e & 15;
+                        const int q = qt * 32 + (lane & 31), key = kt * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                        bb[(((size_t)h * 2 + qt) * 64 + lane) * 32 + e] =
+                            (_Float16)(rb->data[((size_t)h * 64 + q) * 64 + key] * 1.44269504088896f);
+                    }
+    }
+    a.blk_bias = (_Float16*)dalloc(bb.size() * 2, false);
+    if (!a.blk_bias) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+    (void)hipMemcpy(a.blk_bias, bb.data(), bb.size() * 2, hipMemcpyHostToDevice);
+    return M0_OK;
+}
+
 int Net::upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err) {
     const HostTensor* g = get(prefix + ".weight", err);
     if (!g) return M0_ERR_INVALID;
@@ -237,6 +297,7 @@ int Net::finalize(std::string& err) {
             TRY(pack_gemm(a.qkv, p + ".qkv.weight", "", 1, C, P, 3 * C, 3 * P, 0, err, P != C ? cfg_.attention_heads : 0, P / 16));
             TRY(pack_gemm(a.proj, p + ".proj.weight", "", 1, C, P, C, P, 0, err));
             TRY(upload_norm(a.ln, p + ".norm", C, P, err));
+            if (P == 320) TRY(pack_attn_block(a, p, err));
             if (cfg_.attention_relbias) {
                 const HostTensor* rb = get(p + ".rel_bias", err); if (!rb) return M0_ERR_INVALID;
                 if ((int)rb->data.size() != cfg_.attention_heads * 4096) { err = "shape mismatch for rel_bias"; return M0_ERR_INVALID; }
@@ -475,6 +536,8 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
     const char* ftenv = getenv("M0_FUSE_TAIL");          // =0: conv2 + se_gate + ew_board as separate kernels
     const bool fuse_tail = big && C == 320 && !(ftenv && ftenv[0] == '0') &&
                            (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
+    const char* faenv = getenv("M0_FUSE_ATTN");          // =0: qkv GEMM + attn_core + proj GEMM + ew_board as separate kernels
+    const bool fuse_attn = C == 320 && !(faenv && faenv[0] == '0');
     // ew: elementwise glue; y2/gn2 = pre-activated input of the NEXT residual block (its bn1), or null
     auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
                   const float* pos, const NormParams* ln, _Float16* y, float* ost, const NormParams* next_bn1,
@@ -565,6 +628,19 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         } else {
             if (L.skip) continue;
             const AttnW& w = att_[L.index];
+            if (fuse_attn && w.blk_w != nullptr) {
+                // the whole block (qkv, attention, proj, residual, LayerNorm, next block's GroupNorm/act) in one kernel
+                AttnBlockArgs ab;
+                memset(&ab, 0, sizeof(ab));
+                ab.x = xa; ab.wpack = w.blk_w; ab.bias = w.blk_bias; ab.mask = mask_dev_;
+                ab.ln_g = w.ln.gamma; ab.ln_b = w.ln.beta; ab.y = xb;
+                if (const NormParams* nb = next_bn1_after(li)) { ab.y2 = AA_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; }
+                ab.B = Bp; ab.ln_count = C_; ab.act = act; ab.mix = cfg_.attention_unmasked_mix;
+                ab.inv_sqrt_d = 1.f / sqrtf((float)(C_ / cfg_.attention_heads));
+                KCHK(launch_attn_block(ab, st));
+                std::swap(xa, xb);
+                continue;
+            }
             KCHK(run_gemm(w.qkv, xa, QKV_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             AttnArgs aa;
             aa.qkv = QKV_; aa.rel_bias = w.rel_bias; aa.mask = mask_dev_; aa.o = O_;

@@ -78,6 +78,27 @@ struct AttnArgs {
     float inv_sqrt_d;
 };
 
+// attn_block_kernel (attn_block.hip): a whole attention block of the 320-channel trunk in one kernel
+struct AttnBlockArgs {
+    const _Float16* x;       // [B][64][320] trunk
+    const void* wpack;       // attn_block_pack_bytes(): 70 (+3 pad) weight pieces of 12 KB in LDS image order (net.hip)
+    const _Float16* bias;    // [20][2][64][32] rel_bias * log2(e) in accumulator order (zeros when the net has none)
+    const uint64_t* mask;    // [64] bit j of word i = key j visible from query i
+    const float* ln_g;       // LayerNorm [320] (zero beyond ln_count)
+    const float* ln_b;
+    const float* gn2_gamma;  // with y2: GroupNorm16 + act of the next residual block
+    const float* gn2_beta;
+    _Float16* y;             // [B][64][320] LayerNorm(x + attention(x))
+    _Float16* y2;            // [B][64][320] or null
+    int B;                   // boards, even
+    int ln_count;            // real channel count of the LayerNorm
+    int act;                 // ACT_SILU / ACT_RELU (y2)
+    float mix;
+    float inv_sqrt_d;
+};
+hipError_t launch_attn_block(const AttnBlockArgs& a, hipStream_t st);
+size_t attn_block_pack_bytes();
+
 hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st);
 int conv_gemm_tile_n(int Cin, int Npad);
 int conv_gemm_kc(int Cin, int Npad);

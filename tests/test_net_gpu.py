@@ -108,6 +108,42 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
             assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
 
 
+def test_fused_attention_block_matches_split_kernels(monkeypatch):
+    """The whole attention block in one kernel (attn_block.hip: qkv GEMM, scores/softmax/PV, proj GEMM, residual,
+    LayerNorm, the next block's GroupNorm + activation) vs qkv + attn_core + proj + ew_board as four kernels, on a ragged
+    batch, and both against the fp32 oracle.  Variants: the default (relative bias, mix 0.2), masked only / unmasked
+    only branches without relative bias, relu, an attention block as the LAST tower layer (no second output), and the
+    zero-padded 288-channel trunk (18 real heads of 20)."""
+    from matrix0_amd.backend import M0Backend
+    variants = (
+        dict(blocks=6),
+        dict(blocks=6, attention_unmasked_mix=1.0, attention_relbias=False, activation="relu"),
+        dict(blocks=3, attention_unmasked_mix=0.0),
+        dict(blocks=6, channels=288, attention_heads=18),
+    )
+    for extra in variants:
+        cfg = dict(_r24_cfg(), **extra)
+        sd = net_ref.random_state_dict(cfg, seed=5)
+        be = M0Backend.from_state_dict(cfg, sd)
+        g = torch.Generator().manual_seed(12)
+        B = 37
+        x = torch.zeros(B, 19, 8, 8)
+        x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+        x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+        x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+        monkeypatch.setenv("M0_FUSE_ATTN", "0")
+        p_split, v_split = be.infer_np(x.numpy())
+        monkeypatch.setenv("M0_FUSE_ATTN", "1")
+        p_fused, v_fused = be.infer_np(x.numpy())
+        assert np.abs(p_fused - p_split).max() <= 5e-3, extra
+        assert np.abs(v_fused - v_split).max() <= 5e-3, extra
+        p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
+        for p, v in ((p_split, v_split), (p_fused, v_fused)):
+            assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL, extra
+            assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL, extra
+        be.close()
+
+
 def test_shipped_config_288x22_zero_padded_trunk():
     """The reference's shipped config.yaml network (288 channels x 22 blocks, 18 heads, rank-160 policy, attention
     stride 2, leaky value head): the engine zero-pads its trunk to 320 channels so it runs on the MFMA big-tile kernels;
