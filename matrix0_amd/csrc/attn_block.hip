@@ -111,15 +111,15 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     // ---- attention role of this wave: unit = (board, head-in-group), query half
     const int au = w >> 1, aboard = au >> 1, ahl = au & 1, aqt = w & 1;
     const int aq = aqt * 32 + r31;
-    // visibility of key (kt, r) from query aq as an fp16 multiplicand, accumulator order: key = kt*32 + 8(r>>2) + 4 half + (r&3)
-    half2v visr[16];
+    // visibility of key (kt, r) from query aq as a multiplicand, accumulator order: key = kt*32 + 8(r>>2) + 4 half + (r&3)
+    float visf[32];
     {
         const uint64_t m = a.mask[aq];
-        static_for<0, 16>([&](auto i_) __attribute__((always_inline)) {
+        static_for<0, 32>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
-            constexpr int kt = i >> 3, r = (2 * i) & 15;
+            constexpr int kt = i >> 4, r = i & 15;
             const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            visr[i] = half2v{(_Float16)(float)((m >> key) & 1), (_Float16)(float)((m >> (key + 1)) & 1)};
+            visf[i] = (float)((m >> key) & 1);
         });
     }
     float wm_, wu_;   // output weights of the masked / unmasked branch (resnet.py:154-174)
@@ -157,8 +157,27 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         // ---- 1. qkv GEMM of the group: 5 pieces of K = 64
         static_for<0, 5>([&](auto p_) __attribute__((always_inline)) {
             constexpr int p = decltype(p_)::value;
+            // the activation fragments do not depend on the weight DMA: read them ahead of the wait and the barrier
+            half8 xf[2][2];
+            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kk_)::value;
+                constexpr int ks = 2 * p + kk;
+                const int xo = 128 * (ks >> 1) + ((ks & 1) ? xe1 : xe0);
+                xf[kk][0] = *reinterpret_cast<const half8*>(xb0 + xo);
+                xf[kk][1] = *reinterpret_cast<const half8*>(xb1 + xo);
+            });
             if constexpr (p < 3) AB_WAIT(4); else AB_WAIT(8);
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* slot = ring + ((t0 + p) & 3) * AB_PIECE;
+            half8 wf[2][3];
+            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
+                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int kk = decltype(kk_)::value, j = decltype(j_)::value;
+                    wf[kk][j] = *reinterpret_cast<const half8*>(slot + (kk ? wq1 : wq0) + j * 2048);
+                });
+            });
+            asm volatile("" ::: "memory");
             issue(t0 + p + 3);
             if constexpr (p == 2) {
                 // relative-position bias of (head, query half) in accumulator order: 64 B per lane
@@ -170,19 +189,11 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                              "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
                              : "=&v"(bias8[0]), "=&v"(bias8[1]), "=&v"(bias8[2]), "=&v"(bias8[3]) : "v"(bp) : "memory");
             }
-            const char* slot = ring + ((t0 + p) & 3) * AB_PIECE;
             static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
-                constexpr int kk = decltype(kk_)::value;
-                constexpr int ks = 2 * p + kk;
-                const int xo = 128 * (ks >> 1) + ((ks & 1) ? xe1 : xe0);
-                const half8 xf0 = *reinterpret_cast<const half8*>(xb0 + xo);
-                const half8 xf1 = *reinterpret_cast<const half8*>(xb1 + xo);
-                const char* wb = slot + (kk ? wq1 : wq0);
                 static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
-                    constexpr int j = decltype(j_)::value;
-                    const half8 wf = *reinterpret_cast<const half8*>(wb + j * 2048);
-                    qa[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf0, qa[0][j], 0, 0, 0);
-                    qa[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf1, qa[1][j], 0, 0, 0);
+                    constexpr int kk = decltype(kk_)::value, j = decltype(j_)::value;
+                    qa[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], xf[kk][0], qa[0][j], 0, 0, 0);
+                    qa[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], xf[kk][1], qa[1][j], 0, 0, 0);
                 });
             });
         });
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                     const float eu = __builtin_amdgcn_exp2f(d);
                     e[kt][r] = eu;
                     su += eu;
-                    sm += eu * (float)visr[bi >> 1][bi & 1];
+                    sm += eu * visf[bi];
                 });
             });
             su += __shfl_xor(su, 32);
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                     static_for<0, 8>([&](auto u_) __attribute__((always_inline)) {
                         constexpr int u = decltype(u_)::value;
                         constexpr int r = 8 * jb + u, bi = kt * 16 + r;
-                        const float vis = (float)visr[bi >> 1][bi & 1];
+                        const float vis = visf[bi];
                         pf[u] = (_Float16)(e[kt][r] * (vis * cm + cu));
                     });
                     oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt][jb], pf, oacc, 0, 0, 0);
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     const float* par = reinterpret_cast<const float*>(smem + AB_PAR);
     float2* scr = reinterpret_cast<float2*>(smem + AB_RING);            // [8 waves][20][4] GroupNorm partials
     float2* tot = scr + 8 * 20 * 4;                                     // [2 boards][20] (mean, rstd)
+    const float nmr = -mean * rstd;
     static_for<0, 20>([&](auto j_) __attribute__((always_inline)) {
         constexpr int j = decltype(j_)::value;
         const float4 gm = *reinterpret_cast<const float4*>(par + 16 * j + 4 * lq);
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         half4v h;
         static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
-            const float y = (oc[j][r] - mean) * rstd * gmv[r] + btv[r];
+            const float y = fmaf(fmaf(oc[j][r], rstd, nmr), gmv[r], btv[r]);      // (v - mean) rstd gamma + beta, two FMAs
             p1 += y; p2 += y * y;
             h[r] = (_Float16)y;
         });
@@ -370,19 +382,33 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         tot[tid] = make_float2(mu, rsqrtf(vr + 1e-5f));
     }
     __syncthreads();
+    // per (board, channel) scale and shift over the gamma / beta slots (the second GroupNorm's parameters are dead after this)
+    {
+        float* parw = reinterpret_cast<float*>(smem + AB_PAR);
+        float scv[2] = {0.f, 0.f}, shv[2] = {0.f, 0.f};
+        if (tid < 320) {
+            const float g2 = parw[640 + tid], b2 = parw[960 + tid];
+#pragma unroll
+            for (int bd = 0; bd < 2; ++bd) {
+                const float2 mr = tot[bd * 20 + (tid >> 4)];
+                scv[bd] = g2 * mr.y; shv[bd] = b2 - mr.x * scv[bd];
+            }
+        }
+        __syncthreads();
+        if (tid < 320) { parw[tid] = scv[0]; parw[320 + tid] = shv[0]; parw[640 + tid] = scv[1]; parw[960 + tid] = shv[1]; }
+        __syncthreads();
+    }
     static_for<0, 20>([&](auto j_) __attribute__((always_inline)) {
         constexpr int j = decltype(j_)::value;
-        const float2 mr = tot[(w >> 2) * 20 + j];
-        const float4 gm = *reinterpret_cast<const float4*>(par + 640 + 16 * j + 4 * lq);
-        const float4 bt = *reinterpret_cast<const float4*>(par + 960 + 16 * j + 4 * lq);
+        const float4 gm = *reinterpret_cast<const float4*>(par + (w >> 2) * 640 + 16 * j + 4 * lq);
+        const float4 bt = *reinterpret_cast<const float4*>(par + (w >> 2) * 640 + 320 + 16 * j + 4 * lq);
         const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
         const int chunk = 2 * j + (lq >> 1);
         const int pos = (chunk & ~7) | ((chunk ^ tsw) & 7);
         half4v h = *reinterpret_cast<const half4v*>(xrow + pos * 16);
         static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
             constexpr int r = decltype(r_)::value;
-            const float sc = gmv[r] * mr.y;
-            h[r] = (_Float16)act_fast<ACT>((float)h[r] * sc + (btv[r] - mr.x * sc));
+            h[r] = (_Float16)act_fast<ACT>((float)h[r] * gmv[r] + btv[r]);
         });
         *reinterpret_cast<half4v*>(xrow + pos * 16) = h;
     });
