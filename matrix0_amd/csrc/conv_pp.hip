@@ -209,20 +209,23 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
         }
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            auto set_tap = [&](int dy, int dx) __attribute__((always_inline)) {
+            // fragment addresses of tap `tp` in activation buffer `Abuf` (zero square outside the board)
+            auto tap_addr = [&](const char* Abuf, int tp, const char* (&ab)[2], int (&af)[2]) __attribute__((always_inline)) {
+                const int t3 = tp / 3;
+                const int dy = t3 - 1, dx = tp - t3 * 3 - 1;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const int yy = py[mi] + dy, xx = px[mi] + dx;
                     const bool ok = (unsigned)yy < 8u && (unsigned)xx < 8u;
                     const int pp = prow[mi] + dy * 8 + dx;
-                    abase[mi] = ok ? Ab + pp * 128 : Z_lds;
-                    afx[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
+                    ab[mi] = ok ? Abuf + pp * 128 : Z_lds;
+                    af[mi] = ok ? (((pp >> 1) & 7) ^ half) : 0;
                 }
             };
 #ifdef PP_SLIM_TAP
-            if (c == 0 && tap == 0) set_tap(0, 0);          // timing experiment: no per-tap address work (wrong data)
+            if (c == 0 && tap == 0) tap_addr(Ab, 4, abase, afx);   // timing experiment: no per-tap address work (wrong data)
 #else
-            set_tap(tap / 3 - 1, tap - (tap / 3) * 3 - 1);
+            tap_addr(Ab, tap, abase, afx);
 #endif
             static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_)::value;      // 16-deep k slice of the K-tile
@@ -244,8 +247,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
 #endif
                 if constexpr ((j & 1) == 1) {
 #ifndef PP_NO_DMA
-                    issue_next(G_);
+#ifdef PP_DMA_IN_L
+                    issue_next(G_);                     // first placement: in the load section (476 vs 455 us stand-alone)
+#endif
+#ifndef PP_NO_VMWAIT
                     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
 #endif
                 }
 #ifdef PP_DUMMY_VALU
@@ -269,6 +276,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                     constexpr int ni = decltype(ni_)::value;
                     acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb[ni], acc[0][ni], 0, 0, 0);
                     acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb[ni], acc[1][ni], 0, 0, 0);
+#if !defined(PP_DMA_IN_L) && !defined(PP_NO_DMA)
+                    // the next half-tile's DMA is issued in the shadow of the even slice's MFMAs (the issuing wave is
+                    // otherwise waiting for the matrix pipe there); its counted wait stays in the odd slice's load
+                    // section.  The slot it overwrites (half-tile y-1 resp. y) was last read in a load section that both
+                    // groups have left by now.
+                    if constexpr ((j & 1) == 0 && ni == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+#endif
                 });
                 });
                 PP_SETPRIO(0);
