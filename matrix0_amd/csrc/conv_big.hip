@@ -20,6 +20,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // 512-entry register file each), wave tile 64x320: 12 LDS fragment reads per 20 MFMAs instead of 7 per 10.
 template <int TAPS, int EPI, int WNW>
 __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
+    // split K (1x1 only): workgroup row blockIdx.y takes 1/ksplit of the 64-channel chunks and writes an fp32 partial tile
+    const int ksp = (TAPS == 1 && a.ksplit > 1) ? a.ksplit : 1;
+    const int kz = (TAPS == 1 && a.ksplit > 1) ? blockIdx.y : 0;
+    if (ksp > 1) a.out = reinterpret_cast<float*>(a.out) + (size_t)kz * a.Mrows * a.ldo;
     constexpr int NT = 10 / WNW;
     constexpr int NWAVES = 4 * WNW;
     constexpr int WP = 40 / NWAVES;      // weight DMA pieces per wave and stage
@@ -52,8 +56,10 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
     const int m0 = rb * 256;
     const int n0 = nb * 320;
     const int Cin = a.Cin;
-    const int nchunk = Cin >> 6;
-    const int nsteps = nchunk * TAPS;
+    const int nchunk = Cin >> 6;                 // all chunks (the weight layout's stride)
+    const int cchunks = nchunk / ksp;            // this workgroup's chunks, starting at c0
+    const int c0 = kz * cchunks;
+    const int nsteps = cchunks * TAPS;
     const int half = lane >> 5;
 
     if (tid < 8) reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);
@@ -68,13 +74,13 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
             const int q = wave * AP + i;                // 1-KiB piece: squares 8q..8q+7 of the 256-row tile
             const int p = 8 * q + (lane >> 3);
             const int cl = lane & 7;                    // LDS 16-byte chunk this lane fills
-            const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
+            const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)(c0 + chunk) * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
             glds16(src, A_lds + buf * A_BYTES + q * 1024);
         }
     };
     auto issue_W = [&](int step, int buf) {
         const int chunk = step / TAPS, tap = step - chunk * TAPS;
-        const char* src = w_bytes + ((size_t)(tap * nchunk + chunk) * a.Npad + n0) * 128;
+        const char* src = w_bytes + ((size_t)(tap * nchunk + c0 + chunk) * a.Npad + n0) * 128;
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
             const int q = wave * WP + i;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
         const int q = wave * AP + i;
         const int p = 8 * q + (lane >> 3);
         const int cl = lane & 7;
-        const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
+        const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)(c0 + chunk) * 64) * 2 + 16 * (cl ^ ((p >> 1) & 7));
         glds16(src, A_lds + buf * A_BYTES + q * 1024);
     };
 
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
         const bool more2 = s2 < nsteps;
         const int ch2 = s2 / TAPS, tp2 = s2 - ch2 * TAPS;
         const bool newA = more2 && tp2 == 0;
-        const char* wsrc = w_bytes + ((size_t)(tp2 * nchunk + ch2) * a.Npad + n0) * 128;
+        const char* wsrc = w_bytes + ((size_t)(tp2 * nchunk + c0 + ch2) * a.Npad + n0) * 128;
         if (s + 1 < nsteps) set_addr(s + 1);
         // 4th k-step: MFMAs of set 1, next step's first fragments into set 0, stage s+2 DMA pieces in between
         if (s + 1 < nsteps) load_frags(I0{}, I0{});
@@ -212,7 +218,7 @@ static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((a.Mrows / 256) * (a.Npad / 320));
+    dim3 grid((a.Mrows / 256) * (a.Npad / 320), a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW>), grid, dim3(256 * WNW), lds, st, a);
     return hipGetLastError();
 }
@@ -222,7 +228,35 @@ hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
     // WNW = 2 (8 waves).  The 4-wave / 512-register form (WNW = 1) was built and measured: numerically identical,
     // 2x slower with hipcc's schedule (LDS latency exposed with one wave per SIMD, spills) -- not instantiated.
     if (taps != 1 || a.gn_gamma != nullptr) return hipErrorInvalidValue;
+    if (a.ksplit > 1 && ((a.Cin >> 6) % a.ksplit != 0 || !a.out_f32 || a.bias || a.mul || a.epi_act != ACT_NONE || a.out_stats))
+        return hipErrorInvalidValue;
     if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
     const bool general = a.mul != nullptr || a.out_f32 != 0 || a.epi_act != ACT_NONE;   // per-element epilogue
     return general ? launch_conv_big_e<1, 2, 2>(a, st) : launch_conv_big_e<1, 0, 2>(a, st);
+}
+
+// Second pass of a split-K GEMM: fixed-order sum of the partial tiles, bias, activation, fp16.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t MN, int N, const float* __restrict__ bias,
+                                     int act, _Float16* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= MN) return;
+    float4 s = *reinterpret_cast<const float4*>(part + i);
+    for (int z = 1; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * MN + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int n = (int)(i % (size_t)N);
+    if (bias != nullptr) { s.x += bias[n]; s.y += bias[n + 1]; s.z += bias[n + 2]; s.w += bias[n + 3]; }
+    typedef _Float16 half4r __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<half4r*>(out + i) = half4r{(_Float16)act_apply(s.x, act), (_Float16)act_apply(s.y, act),
+                                                 (_Float16)act_apply(s.z, act), (_Float16)act_apply(s.w, act)};
+}
+
+hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* bias, int act, _Float16* out,
+                                hipStream_t st) {
+    if (splits < 1 || N % 4 != 0) return hipErrorInvalidValue;
+    const size_t MN = (size_t)M * N;
+    const unsigned blocks = (unsigned)((MN / 4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, splits, MN, N, bias, act, out);
+    return hipGetLastError();
 }

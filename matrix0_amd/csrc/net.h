@@ -137,6 +137,7 @@ private:
     int pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bkey, int taps, int Cin_real,
                   int Cin_pad, int N_real, int N_pad, int k_perm_ch, std::string& err, int qkv_heads = 0,
                   int qkv_heads_pad = 0);
+    float* SPK_ = nullptr;      // split-K partial tiles [8][Mfc][2C] f32 (value_fc1)
     int pack_attn_block(AttnW& a, const std::string& prefix, std::string& err);
     int upload_norm(NormParams& n, const std::string& prefix, int C_real, int C_pad, std::string& err);
     float* upload_f32(const std::vector<float>& v);

@@ -426,8 +426,9 @@ int Net::ensure_workspace(int B, std::string& err) {
     F2_ = H((size_t)Mfc * ceil_to(2 * C_, 32)); F3_ = H((size_t)Mfc * ceil_to(C_, 32)); F4_ = H((size_t)Mfc * ceil_to(C_, 32));
     SH_ = H(nb * 64 * Cs_); SH2_ = H(nb * 64 * Cs_); SO_ = H(nb * 64 * 32);
     VAL_ = F((size_t)Mfc * 32);
+    SPK_ = F((size_t)8 * Mfc * ceil_to(2 * C_, 32));
     if (!X0_ || !XA_ || !XB_ || !AA_ || !T1_ || !T2_ || !QKV_ || !O_ || !SX_ || !S1_ || !S2_ || !PH_ || !PH2_ || !VH_ ||
-        !VH2_ || !F1_ || !F2_ || !F3_ || !F4_ || !SH_ || !SH2_ || !SO_ || !VAL_) {
+        !VH2_ || !F1_ || !F2_ || !F3_ || !F4_ || !SH_ || !SH2_ || !SO_ || !VAL_ || !SPK_) {
         err = "workspace hipMalloc failed";
         wsB_ = wsM_ = 0;
         return M0_ERR_HIP;
@@ -454,7 +455,20 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
         }
         (void)hipEventRecord(pev_[pev_used_], st);
     }
-    hipError_t rc = launch_conv_gemm(a, g.taps, st);
+    hipError_t rc;
+    // a long-K 1x1 GEMM over few rows (value_fc1: K = 8192, 32 tiles on 256 CUs): split K eight ways into fp32 partial
+    // tiles, then a fixed-order reduction with the bias and the activation
+    const int tiles = (Mrows / 256) * (g.N / 320);
+    const bool splitk = g.taps == 1 && conv_gemm_tile_n(g.Cin, g.N) == 320 && g.Cin >= 4096 && (g.Cin >> 6) % 8 == 0 &&
+                        tiles <= 64 && !out_norm && !mul && !out_stats && !out_f32 && out_scale == 1.f && SPK_ != nullptr &&
+                        (size_t)g.N <= (size_t)ceil_to(2 * C_, 32) && Mrows <= wsM_;
+    if (splitk) {
+        a.out = SPK_; a.bias = nullptr; a.epi_act = ACT_NONE; a.out_f32 = 1; a.ksplit = 8;
+        rc = launch_conv_gemm(a, g.taps, st);
+        if (rc == hipSuccess) rc = launch_splitk_reduce(SPK_, 8, Mrows, g.N, g.bias, epi_act, (_Float16*)out, st);
+    } else {
+        rc = launch_conv_gemm(a, g.taps, st);
+    }
     if (timed) {
         (void)hipEventRecord(pev_[pev_used_ + 1], st);
         pev_used_ += 2;

@@ -23,6 +23,8 @@ struct GemmArgs {
     int epi_act;
     int out_f32;
     float out_scale;
+    int ksplit;              // conv_big_kernel<1>: > 1 = split K over gridDim.y, workgroup z writes its fp32 partial tile to
+                             // out + z * Mrows * ldo floats (out_f32 = 1, no bias / act); reduced by launch_splitk_reduce
     int w_pp;                // 3x3 big tile: w is in conv_pp_kernel's half-tile layout (pack_gemm)
     // residual-block tail fused into the epilogue (conv_tail.h), when res != null: out = res + gate * conv,
     // y2 = epi_act(GroupNorm16(out; gn_gamma, gn_beta)) when y2 != null, gate from se_* when se_w1 != null
@@ -97,6 +99,9 @@ struct AttnBlockArgs {
     float inv_sqrt_d;
 };
 hipError_t launch_attn_block(const AttnBlockArgs& a, hipStream_t st);
+// out[m][n] = act(sum_z part[z][m][n] + bias[n]) as fp16 (fixed summation order), n < N, row stride ld
+hipError_t launch_splitk_reduce(const float* part, int splits, int M, int N, const float* bias, int act, _Float16* out,
+                                hipStream_t st);
 size_t attn_block_pack_bytes();
 
 hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st);
