@@ -2,6 +2,7 @@
 // global_load_lds staging and fused block epilogues).  See net_kernels.hip's header for the design.
 #include "kernel_common.h"
 #include "conv_epilogue.h"
+#include "conv_tail.h"
 
 // ---------------------------------------------------------------------------
 // conv_big: the hot kernel (see file header)
@@ -18,7 +19,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // latency-bound GEMV that a 1-workgroup-per-CU kernel cannot hide -- so those passes stay in ew_board_kernel.)
 // WNW: waves along N.  2: 8 waves (2 per SIMD), wave tile 64x160, <=256 VGPRs.  1: 4 waves (one per SIMD, the whole
 // 512-entry register file each), wave tile 64x320: 12 LDS fragment reads per 20 MFMAs instead of 7 per 10.
-template <int TAPS, int EPI, int WNW>
+template <int TAPS, int EPI, int WNW, int ACT = ACT_NONE>
 __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
     // split K (1x1 only): workgroup row blockIdx.y takes 1/ksplit of the 64-channel chunks and writes an fp32 partial tile
     const int ksp = (TAPS == 1 && a.ksplit > 1) ? a.ksplit : 1;
@@ -205,21 +206,23 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                      // the epilogue stages the output tile over the A/W buffers
-    conv_tile_epilogue<EPI, ACT_NONE, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
+    // EPI 5: out = res + act(GroupNorm16(conv)) (+ the next GroupNorm's second output), conv_tail.h's PRE form
+    if constexpr (EPI == 5) conv_tail_epilogue<ACT, true>(acc, a, smem, m0, wm, wn, wave, lane);
+    else conv_tile_epilogue<EPI, ACT_NONE, NT>(acc, a, smem + wave * (NT * 64 * 64), m0, n0, wm, wn, lane);
 }
 
-template <int TAPS, int EPI, int WNW>
+template <int TAPS, int EPI, int WNW, int ACT = ACT_NONE>
 static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW, ACT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((a.Mrows / 256) * (a.Npad / 320), a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW>), grid, dim3(256 * WNW), lds, st, a);
+    hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW, ACT>), grid, dim3(256 * WNW), lds, st, a);
     return hipGetLastError();
 }
 
@@ -227,7 +230,17 @@ hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
     // 1x1 convs whose N is a multiple of 320 (qkv, proj).  3x3: conv_pp_kernel (conv_pp.hip).
     // WNW = 2 (8 waves).  The 4-wave / 512-register form (WNW = 1) was built and measured: numerically identical,
     // 2x slower with hipcc's schedule (LDS latency exposed with one wave per SIMD, spills) -- not instantiated.
-    if (taps != 1 || a.gn_gamma != nullptr) return hipErrorInvalidValue;
+    if (taps != 1) return hipErrorInvalidValue;
+    if (a.res != nullptr) {   // x + act(GroupNorm16(conv1x1(x))) in the epilogue (piece-square-table conv of the chess features)
+        if (a.pre_gamma == nullptr || a.se_w1 != nullptr || a.N != 320 || a.Npad != 320 || a.ldo != 320 || a.bias != nullptr ||
+            a.out_stats != nullptr || a.mul != nullptr || a.out_f32 != 0 || a.ksplit > 1 || (a.y2 != nullptr && a.gn_gamma == nullptr))
+            return hipErrorInvalidValue;
+        if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+        if (a.epi_act == ACT_SILU) return launch_conv_big_e<1, 5, 2, ACT_SILU>(a, st);
+        if (a.epi_act == ACT_RELU) return launch_conv_big_e<1, 5, 2, ACT_RELU>(a, st);
+        return hipErrorInvalidValue;
+    }
+    if (a.gn_gamma != nullptr) return hipErrorInvalidValue;
     if (a.ksplit > 1 && ((a.Cin >> 6) % a.ksplit != 0 || !a.out_f32 || a.bias || a.mul || a.epi_act != ACT_NONE || a.out_stats))
         return hipErrorInvalidValue;
     if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets

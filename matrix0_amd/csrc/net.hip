@@ -596,8 +596,19 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
     if (cfg_.chess_features) {
         KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, posenc_, nullptr, xa, nullptr, nullptr, nullptr, C, Bp));
         if (cfg_.piece_square_tables) {
-            KCHK(run_gemm(pst_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-            KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, nullptr, nullptr, C, Bp));
+            if (fuse_tail) {
+                // piece-square-table 1x1 conv + GroupNorm/act + residual add in one kernel
+                GemmArgs pa;
+                memset(&pa, 0, sizeof(pa));
+                pa.in = xa; pa.w = pst_.w; pa.out = xb;
+                pa.Mrows = Mc; pa.Mvalid = Mc; pa.Cin = pst_.Cin; pa.N = pst_.N; pa.Npad = pst_.N; pa.ldo = pst_.N;
+                pa.epi_act = act; pa.out_scale = 1.f;
+                pa.res = xa; pa.pre_gamma = pst_n_.gamma; pa.pre_beta = pst_n_.beta;
+                KCHK(launch_conv_gemm(pa, 1, st));
+            } else {
+                KCHK(run_gemm(pst_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+                KCHK(ew(T1_, S1_, &pst_n_, nullptr, xa, nullptr, nullptr, xb, nullptr, nullptr, nullptr, C, Bp));
+            }
             std::swap(xa, xb);
         }
         if (fuse_tail) {
