@@ -332,6 +332,16 @@ __global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
         shl[i] = gn ? sh[c0 + i] : 0.f;
     });
     float x[4][8];
+    float pe[4][8];                                      // positional encoding [64][C] f32 (stem only): two 16-byte loads per square
+    if (a.posenc) {
+        static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_)::value;
+            const float4 p0 = *reinterpret_cast<const float4*>(a.posenc + (sg * 4 + k) * C + c0);
+            const float4 p1 = *reinterpret_cast<const float4*>(a.posenc + (sg * 4 + k) * C + c0 + 4);
+            pe[k][0] = p0.x; pe[k][1] = p0.y; pe[k][2] = p0.z; pe[k][3] = p0.w;
+            pe[k][4] = p1.x; pe[k][5] = p1.y; pe[k][6] = p1.z; pe[k][7] = p1.w;
+        });
+    }
     static_for<0, 4>([&](auto k_) __attribute__((always_inline)) {
         constexpr int k = decltype(k_)::value;
         static_for<0, 8>([&](auto i_) __attribute__((always_inline)) {
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(768) void ew_board_kernel(EwArgs a) {
             if (gn) v = act_apply(v * scl[i] + shl[i], a.act);
             else if (se) v *= scl[i];
             v += (float)rv[k][i];
-            if (a.posenc) v += a.posenc[(sg * 4 + k) * C + c0 + i];
+            if (a.posenc) v += pe[k][i];
             x[k][i] = v;
         });
     });
