@@ -189,29 +189,34 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         int node = root, depth = 0;
         int prev_from = -1, prev_to = -1;
         if (lane == 0) path[0] = root;
+        // One round of dependent loads per level: the children scan also fetches every candidate's own node fields
+        // (children ARE nodes), and the winner's are broadcast -- the next level starts without loading its node.
+        int nc = A.nch[node], cb = A.cbase[node], nn = A.n[node];
+        double nq = A.q[node];
         while (true) {
-            const int nc = A.nch[node];
             if (nc <= 0 || depth >= M0_MAX_DEPTH - 1) break;
-            const int cb = A.cbase[node];
-            const double nq = A.q[node];
-            const int nn = A.n[node];
             const double sq = sqrt((double)(nn > 1 ? nn : 1));
             const double eff = cpuct_at(c, depth);
             double best = -1e9;
             int bi = -1;
+            int b_nch = 0, b_cb = 0, b_n = 0;
+            double b_q = 0.0;
+            Move b_mv = 0;
             for (int i = lane; i < nc; i += 64) {
                 const int ci = cb + i;
                 const int cn = A.n[ci];
-                const double qq = cn == 0 ? nq - c.fpu_reduction : A.q[ci];
+                const double cq = A.q[ci];
+                const int c_nch = A.nch[ci], c_cb = A.cbase[ci];
+                const Move m = A.mv[ci];
+                const double qq = cn == 0 ? nq - c.fpu_reduction : cq;
                 const double u = eff * A.prior[ci] * (sq / (1.0 + (double)cn));
                 double sc = qq + u;
                 if (c.no_instant_backtrack && depth >= 1) {
-                    const Move m = A.mv[ci];
                     if (mv_from(m) == prev_to && mv_to(m) == prev_from) sc -= 0.01;
                 }
                 if (c.virtual_loss_active && c.virtual_loss > 0.0) sc -= (double)A.vl[ci] * c.virtual_loss;
                 sc += (u01(seedj, ctrj + (uint64_t)i) - 0.5) * jit;
-                if (sc > best) { best = sc; bi = i; }
+                if (sc > best) { best = sc; bi = i; b_nch = c_nch; b_cb = c_cb; b_n = cn; b_q = cq; b_mv = m; }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(best, off);
@@ -221,7 +226,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             ctrj += (uint64_t)nc;
             if (bi < 0) bi = 0;
             const int child = cb + bi;
-            const Move m = A.mv[child];
+            // the lane that scanned child bi (i = lane + 64 k) holds its fields iff its own best is bi
+            const int wl = bi & 63;
+            nc = __shfl(b_nch, wl); cb = __shfl(b_cb, wl); nn = __shfl(b_n, wl); nq = __shfl(b_q, wl);
+            const Move m = (Move)__shfl((int)b_mv, wl);
             const uint64_t k = tkey(pos);
             const bool irr = irreversible(pos, m);
             if (lane == 0) { pkey[depth] = k; pirr[depth] = irr ? 1 : 0; }
