@@ -104,14 +104,16 @@ __device__ void encode_nhwc(const Pos& p, _Float16* dst /*[64][32]*/, int lane) 
     o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
 }
 
-__device__ void backprop(const Arena& A, const int* path, int depth, double value) {   // lane-0 caller
-    double v = fmax(-1.0, fmin(1.0, value));
-    for (int d = depth; d >= 0; --d) {
+// MCTS._backpropagate (mcts.py:946-953): the leaf gets +v, its parent -v, ...  The nodes of a path are distinct, so
+// every level is independent: lane d updates level d (all levels' loads in flight at once instead of a chain of
+// dependent read-modify-writes by one lane); the arithmetic per node is that of the sequential loop (negation is exact).
+__device__ void backprop(const Arena& A, const int* path, int depth, double value, int lane) {   // whole-wave caller
+    const double v = fmax(-1.0, fmin(1.0, value));
+    for (int d = lane; d <= depth; d += 64) {
         const int nd = path[d];
         const int nn = A.n[nd] + 1;
-        const double ww = A.w[nd] + v;
+        const double ww = A.w[nd] + (((depth - d) & 1) ? -v : v);
         A.n[nd] = nn; A.w[nd] = ww; A.q[nd] = ww / (double)nn;
-        v = -v;
     }
 }
 
@@ -272,9 +274,9 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             Sample smp; smp.pos = pos; smp.kind = term ? 3 : 1; smp.leaf = node; smp.depth = depth; smp.row = row;
             smp.nlegal = nlegal;
             S[s] = smp;
-            if (term) backprop(A, path, depth, tv);     // mcts.py:747-751: terminal leaves back up immediately
         }
-        __syncthreads();
+        __syncthreads();                                 // path[] (lane 0) before the wave reads it
+        if (term) { backprop(A, path, depth, tv, lane); __syncthreads(); }   // mcts.py:747-751: terminal leaves back up immediately
     }
     if (lane == 0) { gd->ctr_jitter = ctrj; gd->nsamples = nleaf; }
 }
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
             }
             ++evals;
             if (kind == 1) {
-                if (lane == 0) backprop(A, path, depth, (double)v);
+                backprop(A, path, depth, (double)v, lane);
                 ++sims;
             } else {
                 double rv = fmax(-1.0, fmin(1.0, (double)v));
