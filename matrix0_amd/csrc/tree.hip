@@ -67,11 +67,109 @@ __device__ __forceinline__ Arena arena_of(const TreeArrays& t, int g, int half) 
     return a;
 }
 
-// Legal moves in generation order, the legality test (make + king-attack) spread one move per lane:
-// pseudo-legal list (sequential, uniform across lanes, cheap bitboard work) -> per-lane legal_after() ->
-// order-preserving ballot compaction.  Same list as gen_legal() (tests/test_chess_core_host.py).
+// Exclusive prefix sum over the wave's lanes (lane 0 first) of three packed 10-bit counters; `total` = wave sum.
+__device__ __forceinline__ uint32_t wave_excl_scan3(uint32_t v, int lane, uint32_t& total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off);
+        if (lane >= off) incl += u;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// Pseudo-legal moves in python-chess generation order (chess_core.h gen_moves<false>), one SQUARE per lane:
+// lane L works square 63 - L, so ascending lanes are python-chess's scan_reversed order.  Per category (piece moves by
+// from-square; pawn captures by from-square; single pushes, double pushes by to-square; en passant by from-square)
+// every lane counts its moves, three packed prefix sums give its output offsets, and it writes its own moves; the
+// check-evasion king moves (first) and castling (after the pieces) are uniform work.  gen_moves<false> on every lane was
+// 33 k cycles per leaf (the pseudo-legal list built 64 times over, sequentially).
+__device__ int gen_pseudo_wave(const Pos& p, Move* out, int lane) {
+    const int us = p.turn, them = us ^ 1;
+    const uint64_t own = p.occ[us], theirs = p.occ[them], o = own | theirs;
+    const int ksq = king_sq(p, us);
+    const bool chk = ksq >= 0 && attacked(p, ksq, them);
+    const int s = 63 - lane;
+    const uint64_t sb = bit(s);
+    const uint64_t pawns = p.bb[PAWN] & own;
+    // --- check evasion: the king's moves come first and the king leaves the piece scan
+    int n0 = 0;
+    if (chk) {
+        uint64_t t = king_att(ksq) & ~own;
+        n0 = popc(t);
+        if (lane == 0) { int j = 0; while (t) { const int to = msb(t); t &= ~bit(to); out[j++] = mk_move(ksq, to, 0); } }
+    }
+    // --- category A: non-pawn pieces
+    uint64_t tA = 0;
+    if ((own & ~p.bb[PAWN] & sb) && !(chk && s == ksq)) tA = piece_targets(p, s, piece_type_at(p, s));
+    const uint32_t cA = (uint32_t)popc(tA);
+    // --- castling (uniform), after the pieces
+    Move cz[2];
+    int ncz = 0;
+    if (!chk && ksq >= 0) {
+        const int cr = clean_cr(p);
+        const int base = us == WHITE ? 0 : 56;
+        if (ksq == base + 4) {
+            const int kbit = us == WHITE ? CR_WK : CR_BK, qbit = us == WHITE ? CR_WQ : CR_BQ;
+            if ((cr & kbit) && !(o & (bit(base + 5) | bit(base + 6))) && !attacked(p, base + 5, them) &&
+                !attacked(p, base + 6, them))
+                cz[ncz++] = mk_move(ksq, base + 6, 0);
+            if ((cr & qbit) && !(o & (bit(base + 1) | bit(base + 2) | bit(base + 3))) && !attacked(p, base + 3, them) &&
+                !attacked(p, base + 2, them))
+                cz[ncz++] = mk_move(ksq, base + 2, 0);
+        }
+    }
+    // --- category C: pawn captures (from-square s), promotions expand to 4
+    const uint64_t tC = (pawns & sb) ? (pawn_att(s, us) & theirs) : 0;
+    const uint64_t promo_rank = RANK_1 | RANK_8;
+    const uint32_t cC = (uint32_t)(popc(tC & ~promo_rank) + 4 * popc(tC & promo_rank));
+    // --- category D / E: single and double pushes (to-square s)
+    const uint64_t single = (us == WHITE ? pawns << 8 : pawns >> 8) & ~o;
+    const uint64_t dbl = (us == WHITE ? single << 8 : single >> 8) & ~o & (us == WHITE ? (RANK_1 << 24) : (RANK_1 << 32));
+    const uint32_t cD = (single & sb) ? ((sb & promo_rank) ? 4u : 1u) : 0u;
+    const uint32_t cE = (dbl & sb) ? 1u : 0u;
+    // --- category F: en passant (from-square s)
+    uint64_t epc = 0;
+    if (p.ep >= 0 && !(o & bit(p.ep))) epc = pawns & pawn_att(p.ep, them) & (us == WHITE ? (RANK_1 << 32) : (RANK_1 << 24));
+    const uint32_t cF = (epc & sb) ? 1u : 0u;
+    // --- offsets
+    uint32_t tot1, tot2;
+    const uint32_t ex1 = wave_excl_scan3(cA | (cC << 10) | (cD << 20), lane, tot1);
+    const uint32_t ex2 = wave_excl_scan3(cE | (cF << 10), lane, tot2);
+    const int nA = tot1 & 1023, nC = (tot1 >> 10) & 1023, nD = (tot1 >> 20) & 1023, nE = tot2 & 1023, nF = (tot2 >> 10) & 1023;
+    const int baseA = n0, baseZ = baseA + nA, baseC = baseZ + ncz, baseD = baseC + nC, baseE = baseD + nD, baseF = baseE + nE;
+    {
+        int j = baseA + (int)(ex1 & 1023);
+        uint64_t t = tA;
+        while (t) { const int to = msb(t); t &= ~bit(to); out[j++] = mk_move(s, to, 0); }
+    }
+    if (lane == 0) for (int i = 0; i < ncz; ++i) out[baseZ + i] = cz[i];
+    {
+        int j = baseC + (int)((ex1 >> 10) & 1023);
+        uint64_t t = tC;
+        while (t) {
+            const int to = msb(t); t &= ~bit(to);
+            if (bit(to) & promo_rank) { out[j++] = mk_move(s, to, 4); out[j++] = mk_move(s, to, 3); out[j++] = mk_move(s, to, 2); out[j++] = mk_move(s, to, 1); }
+            else out[j++] = mk_move(s, to, 0);
+        }
+    }
+    if (cD) {
+        int j = baseD + (int)((ex1 >> 20) & 1023);
+        const int from = s + (us == WHITE ? -8 : 8);
+        if (cD == 4) { out[j++] = mk_move(from, s, 4); out[j++] = mk_move(from, s, 3); out[j++] = mk_move(from, s, 2); out[j++] = mk_move(from, s, 1); }
+        else out[j] = mk_move(from, s, 0);
+    }
+    if (cE) out[baseE + (int)(ex2 & 1023)] = mk_move(s + (us == WHITE ? -16 : 16), s, 0);
+    if (cF) out[baseF + (int)((ex2 >> 10) & 1023)] = mk_move(s, p.ep, 0);
+    return baseF + nF;
+}
+
+// Legal moves in generation order: the pseudo-legal list (one square per lane, above), then the legality test
+// (make + king-attack) spread one move per lane and an order-preserving ballot compaction.  Same list as gen_legal()
+// (tests/test_chess_core_host.py pins gen_legal; tests/test_encoding_gpu.py compares this one on 10 000 positions).
 __device__ int gen_legal_wave(const Pos& p, Move* out_lds, Move* tmp_lds, int lane) {
-    const int np = gen_pseudo(p, tmp_lds);
+    const int np = gen_pseudo_wave(p, tmp_lds, lane);
     __syncthreads();
     int base = 0;
     for (int k0 = 0; k0 < np; k0 += 64) {
@@ -558,6 +656,7 @@ hipError_t launch_advance(const TreeDev& d, const int* game_ids_dev, const int* 
 __global__ __launch_bounds__(64) void encode_positions_kernel(const Pos* pos, int n, float* planes, _Float16* nhwc,
                                                               uint8_t* mask, int32_t* nlegal, uint16_t* moves, int32_t* idxs) {
     __shared__ Move smoves[M0_MAX_MOVES];
+    __shared__ Move spseudo[M0_MAX_MOVES];
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     const Pos p = pos[i];
@@ -571,7 +670,7 @@ __global__ __launch_bounds__(64) void encode_positions_kernel(const Pos* pos, in
         for (int k = 0; k < 7; ++k) o[(12 + k) * 64 + lane] = c7[k];
     }
     if (nhwc) encode_nhwc(p, nhwc + (size_t)i * 64 * 32, lane);
-    const int k = gen_legal(p, smoves);
+    const int k = gen_legal_wave(p, smoves, spseudo, lane);   // the search's generator (same list as gen_legal)
     __syncthreads();
     if (mask) for (int j = lane; j < 4672; j += 64) mask[(size_t)i * 4672 + j] = 0;
     __syncthreads();
