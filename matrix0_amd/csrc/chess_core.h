@@ -86,9 +86,22 @@ M0_HD uint64_t bishop_att(int s, uint64_t occ) { return ray(s, occ, 1, 1) | ray(
 M0_HD uint64_t rook_att(int s, uint64_t occ) { return ray(s, occ, 1, 0) | ray(s, occ, -1, 0) | ray(s, occ, 0, 1) | ray(s, occ, 0, -1); }
 
 M0_HD uint64_t occ_all(const Pos& p) { return p.occ[0] | p.occ[1]; }
+// Colour- / type-indexed access without run-time array indexing: with p.occ[c] / p.bb[t] and a run-time index hipcc
+// keeps the whole position in scratch memory on the device (every access a memory round trip in the tree kernels).
+M0_HD uint64_t occ_of(const Pos& p, int c) { return c ? p.occ[1] : p.occ[0]; }
+M0_HD void occ_and(Pos& p, int c, uint64_t m) { p.occ[0] &= c ? ~0ull : m; p.occ[1] &= c ? m : ~0ull; }
+M0_HD void occ_or(Pos& p, int c, uint64_t m) { p.occ[0] |= c ? 0ull : m; p.occ[1] |= c ? m : 0ull; }
+M0_HD void bb_and(Pos& p, int t, uint64_t m) {
+    p.bb[0] &= t == 0 ? m : ~0ull; p.bb[1] &= t == 1 ? m : ~0ull; p.bb[2] &= t == 2 ? m : ~0ull;
+    p.bb[3] &= t == 3 ? m : ~0ull; p.bb[4] &= t == 4 ? m : ~0ull; p.bb[5] &= t == 5 ? m : ~0ull;
+}
+M0_HD void bb_or(Pos& p, int t, uint64_t m) {
+    p.bb[0] |= t == 0 ? m : 0ull; p.bb[1] |= t == 1 ? m : 0ull; p.bb[2] |= t == 2 ? m : 0ull;
+    p.bb[3] |= t == 3 ? m : 0ull; p.bb[4] |= t == 4 ? m : 0ull; p.bb[5] |= t == 5 ? m : 0ull;
+}
 
 M0_HD bool attacked(const Pos& p, int s, int by) {
-    const uint64_t them = p.occ[by];
+    const uint64_t them = occ_of(p, by);
     if (pawn_att(s, by ^ 1) & p.bb[PAWN] & them) return true;
     if (knight_att(s) & p.bb[KNIGHT] & them) return true;
     if (king_att(s) & p.bb[KING] & them) return true;
@@ -99,7 +112,7 @@ M0_HD bool attacked(const Pos& p, int s, int by) {
 }
 
 M0_HD int king_sq(const Pos& p, int c) {
-    uint64_t k = p.bb[KING] & p.occ[c];
+    uint64_t k = p.bb[KING] & occ_of(p, c);
     return k ? msb(k) : -1;
 }
 M0_HD bool in_check(const Pos& p) {
@@ -108,8 +121,11 @@ M0_HD bool in_check(const Pos& p) {
 }
 M0_HD int piece_type_at(const Pos& p, int s) {
     uint64_t b = bit(s);
-    for (int t = 0; t < 6; ++t) if (p.bb[t] & b) return t;
-    return -1;
+    // (branch-free, constant indices)
+    int r = -1;
+    r = (p.bb[5] & b) ? 5 : r; r = (p.bb[4] & b) ? 4 : r; r = (p.bb[3] & b) ? 3 : r;
+    r = (p.bb[2] & b) ? 2 : r; r = (p.bb[1] & b) ? 1 : r; r = (p.bb[0] & b) ? 0 : r;
+    return r;
 }
 
 // clean_castling_rights(): right needs its rook on the corner and the king on e1/e8
@@ -139,18 +155,18 @@ M0_HD void make_move(Pos& p, Move m) {
     const int us = p.turn, them = us ^ 1;
     const uint64_t fb = bit(from), tb = bit(to);
     const int type = piece_type_at(p, from);
-    const bool capture = (p.occ[them] & tb) != 0;
+    const bool capture = (occ_of(p, them) & tb) != 0;
     const bool zeroing = type == PAWN || capture;
     const int ep_old = p.ep;
     p.ep = -1;
     p.cr &= ~(cr_mask_for_square(from) | cr_mask_for_square(to));
     if (type == KING) p.cr &= us == WHITE ? ~(CR_WK | CR_WQ) : ~(CR_BK | CR_BQ);
     if (capture) {
-        for (int t = 0; t < 6; ++t) p.bb[t] &= ~tb;
-        p.occ[them] &= ~tb;
+        p.bb[0] &= ~tb; p.bb[1] &= ~tb; p.bb[2] &= ~tb; p.bb[3] &= ~tb; p.bb[4] &= ~tb; p.bb[5] &= ~tb;
+        occ_and(p, them, ~tb);
     }
-    p.bb[type] &= ~fb;
-    p.occ[us] &= ~fb;
+    bb_and(p, type, ~fb);
+    occ_and(p, us, ~fb);
     if (type == PAWN) {
         const int diff = to - from;
         if (diff == 16 && (from >> 3) == 1) p.ep = (int8_t)(from + 8);
@@ -158,7 +174,7 @@ M0_HD void make_move(Pos& p, Move m) {
         else if (to == ep_old && !capture && (diff == 7 || diff == 9 || diff == -7 || diff == -9)) {
             const uint64_t cb = bit(to + (us == WHITE ? -8 : 8));
             p.bb[PAWN] &= ~cb;
-            p.occ[them] &= ~cb;
+            occ_and(p, them, ~cb);
         }
     }
     if (type == KING && ((to & 7) - (from & 7) == 2 || (to & 7) - (from & 7) == -2)) {
@@ -166,11 +182,11 @@ M0_HD void make_move(Pos& p, Move m) {
         uint64_t rf, rt;
         if ((to & 7) == 6) { rf = bit(r + 7); rt = bit(r + 5); } else { rf = bit(r); rt = bit(r + 3); }
         p.bb[ROOK] = (p.bb[ROOK] & ~rf) | rt;
-        p.occ[us] = (p.occ[us] & ~rf) | rt;
+        occ_and(p, us, ~rf); occ_or(p, us, rt);
     }
     const int placed = promo ? promo : type;   // promo codes 1..4 == KNIGHT..QUEEN
-    p.bb[placed] |= tb;
-    p.occ[us] |= tb;
+    bb_or(p, placed, tb);
+    occ_or(p, us, tb);
     p.halfmove = zeroing ? 0 : (uint16_t)(p.halfmove + 1);
     if (us == BLACK) p.fullmove = (uint16_t)(p.fullmove + 1);
     p.turn = (uint8_t)them;
@@ -208,7 +224,7 @@ M0_HD uint64_t piece_targets(const Pos& p, int from, int type) {
         case QUEEN: a = bishop_att(from, o) | rook_att(from, o); break;
         default: a = king_att(from); break;
     }
-    return a & ~p.occ[p.turn];
+    return a & ~occ_of(p, p.turn);
 }
 template <bool LEGAL>
 M0_HD int emit_piece(const Pos& p, Move* out, int n, int from) {
@@ -224,7 +240,7 @@ template <bool LEGAL>
 M0_HD int gen_moves(const Pos& p, Move* out) {
     int n = 0;
     const int us = p.turn, them = us ^ 1;
-    const uint64_t own = p.occ[us], o = occ_all(p);
+    const uint64_t own = occ_of(p, us), o = occ_all(p);
     const int ksq = king_sq(p, us);
     const bool chk = ksq >= 0 && attacked(p, ksq, them);
     if (chk) n = emit_piece<LEGAL>(p, out, n, ksq);
@@ -248,7 +264,7 @@ M0_HD int gen_moves(const Pos& p, Move* out) {
     uint64_t c = pawns;
     while (c) {
         int s = msb(c); c &= ~bit(s);
-        uint64_t t = pawn_att(s, us) & p.occ[them];
+        uint64_t t = pawn_att(s, us) & occ_of(p, them);
         while (t) { int to = msb(t); t &= ~bit(to); n = emit_promos<LEGAL>(p, out, n, s, to); }
     }
     uint64_t single = (us == WHITE ? pawns << 8 : pawns >> 8) & ~o;
@@ -287,10 +303,10 @@ M0_HD bool any_legal(const Pos& p) {
 }
 
 M0_HD bool insufficient_side(const Pos& p, int c) {
-    const uint64_t own = p.occ[c];
+    const uint64_t own = occ_of(p, c);
     if (own & (p.bb[PAWN] | p.bb[ROOK] | p.bb[QUEEN])) return false;
     if (own & p.bb[KNIGHT])
-        return popc(own) <= 2 && !(p.occ[c ^ 1] & ~p.bb[KING] & ~p.bb[QUEEN]);
+        return popc(own) <= 2 && !(occ_of(p, c ^ 1) & ~p.bb[KING] & ~p.bb[QUEEN]);
     if (own & p.bb[BISHOP]) {
         const bool same = !(p.bb[BISHOP] & DARK_SQ) || !(p.bb[BISHOP] & ~DARK_SQ);
         return same && !p.bb[PAWN] && !p.bb[KNIGHT];
@@ -309,6 +325,7 @@ M0_HD uint64_t mix64(uint64_t x) {
 }
 M0_HD uint64_t tkey(const Pos& p) {
     uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
     for (int t = 0; t < 6; ++t) h = mix64(h ^ p.bb[t]) + 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1);
     h = mix64(h ^ p.occ[WHITE]);
     h = mix64(h ^ p.occ[BLACK] ^ 0x5851F42D4C957F2Dull);
@@ -320,7 +337,7 @@ M0_HD uint64_t tkey(const Pos& p) {
 M0_HD bool irreversible(const Pos& before, Move m) {
     const int from = mv_from(m), to = mv_to(m);
     const int type = piece_type_at(before, from);
-    if (type == PAWN || (before.occ[before.turn ^ 1] & bit(to))) return true;
+    if (type == PAWN || (occ_of(before, before.turn ^ 1) & bit(to))) return true;
     const int cr0 = clean_cr(before);
     int cr1 = cr0 & ~(cr_mask_for_square(from) | cr_mask_for_square(to));
     if (type == KING) cr1 &= before.turn == WHITE ? ~(CR_WK | CR_WQ) : ~(CR_BK | CR_BQ);

@@ -68,7 +68,7 @@ inline bool can_claim_fifty(const Pos& p) {
         const int n = gen_legal(p, mv);
         for (int i = 0; i < n; ++i) {
             const int from = mv_from(mv[i]), to = mv_to(mv[i]);
-            const bool zeroing = piece_type_at(p, from) == PAWN || (p.occ[p.turn ^ 1] & bit(to));
+            const bool zeroing = piece_type_at(p, from) == PAWN || (occ_of(p, p.turn ^ 1) & bit(to));
             if (!zeroing) {
                 Pos q = p;
                 make_move(q, mv[i]);

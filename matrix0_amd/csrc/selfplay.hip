@@ -419,7 +419,7 @@ static std::string san_of(const Pos& p, Move m, const Move* legal, int nlegal) {
     if (pt == KING && abs((to & 7) - (from & 7)) == 2) {
         s = (to & 7) > (from & 7) ? "O-O" : "O-O-O";
     } else {
-        const bool capture = ((p.occ[p.turn ^ 1] >> to) & 1ull) || (pt == PAWN && (from & 7) != (to & 7));
+        const bool capture = ((occ_of(p, p.turn ^ 1) >> to) & 1ull) || (pt == PAWN && (from & 7) != (to & 7));
         if (pt != PAWN) {
             s += "NBRQK"[pt - 1];
             bool any = false, same_file = false, same_rank = false;

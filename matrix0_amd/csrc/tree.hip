@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan3(uint32_t v, int lane, uint32
 // 33 k cycles per leaf (the pseudo-legal list built 64 times over, sequentially).
 __device__ int gen_pseudo_wave(const Pos& p, Move* out, int lane) {
     const int us = p.turn, them = us ^ 1;
-    const uint64_t own = p.occ[us], theirs = p.occ[them], o = own | theirs;
+    const uint64_t own = occ_of(p, us), theirs = occ_of(p, them), o = own | theirs;
     const int ksq = king_sq(p, us);
     const bool chk = ksq >= 0 && attacked(p, ksq, them);
     const int s = 63 - lane;
