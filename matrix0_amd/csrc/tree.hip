@@ -398,8 +398,16 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
     // legal moves of the leaf come from select (same position, same order): no second move generation
     if (n <= 0) return true;
     // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
+    // (16-byte loads, all of a lane's 19 in flight together: one memory latency instead of 73 dependent-looking ones)
     bool bad = false;
-    for (int j = lane; j < 4672; j += 64) { float x = lg[j]; if (!isfinite(x)) bad = true; }
+    {
+        const float4* lg4 = reinterpret_cast<const float4*>(lg);       // 4672 floats = 1168 float4, rows are 16-byte aligned
+        float4 v[19];
+#pragma unroll
+        for (int k = 0; k < 19; ++k) { const int j = lane + 64 * k; v[k] = j < 1168 ? lg4[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < 19; ++k) bad = bad || !isfinite(v[k].x) || !isfinite(v[k].y) || !isfinite(v[k].z) || !isfinite(v[k].w);
+    }
     bad = __any(bad);
     float pr[4];
     int idx[4];
@@ -555,12 +563,13 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
         }
     }
     // release virtual losses of the whole batch (the reference's inflight dict dies with the batch)
-    if (c.virtual_loss_active && lane == 0) {
-        for (int s = 0; s < ns; ++s) {
+    // (integer atomics: one lane per sample, any order gives the same counts)
+    if (c.virtual_loss_active) {
+        for (int s = lane; s < ns; s += 64) {
             const int kind = S[s].kind;
             if (kind == 1 || kind == 3) {
                 const int* path = P + (size_t)s * M0_MAX_DEPTH;
-                for (int dd = 1; dd <= S[s].depth; ++dd) A.vl[path[dd]] -= 1;
+                for (int dd = 1; dd <= S[s].depth; ++dd) atomicSub(&A.vl[path[dd]], 1);
             }
         }
     }
