@@ -401,12 +401,17 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
     // (16-byte loads, all of a lane's 19 in flight together: one memory latency instead of 73 dependent-looking ones)
     bool bad = false;
     {
-        const float4* lg4 = reinterpret_cast<const float4*>(lg);       // 4672 floats = 1168 float4, rows are 16-byte aligned
-        float4 v[19];
+        const uint4* lg4 = reinterpret_cast<const uint4*>(lg);         // 4672 floats = 1168 x 16 B, rows are 16-byte aligned
+        uint4 v[19];
 #pragma unroll
-        for (int k = 0; k < 19; ++k) { const int j = lane + 64 * k; v[k] = j < 1168 ? lg4[j] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < 19; ++k) { const int j = lane + 64 * k; v[k] = lg4[j < 1168 ? j : 1167]; }   // unconditional loads
+        uint32_t acc = 0;                                               // all-ones exponent = inf or nan; no short-circuit
 #pragma unroll
-        for (int k = 0; k < 19; ++k) bad = bad || !isfinite(v[k].x) || !isfinite(v[k].y) || !isfinite(v[k].z) || !isfinite(v[k].w);
+        for (int k = 0; k < 19; ++k) {
+            acc |= (uint32_t)((v[k].x & 0x7f800000u) == 0x7f800000u) | (uint32_t)((v[k].y & 0x7f800000u) == 0x7f800000u) |
+                   (uint32_t)((v[k].z & 0x7f800000u) == 0x7f800000u) | (uint32_t)((v[k].w & 0x7f800000u) == 0x7f800000u);
+        }
+        bad = acc != 0;
     }
     bad = __any(bad);
     float pr[4];

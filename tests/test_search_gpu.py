@@ -92,6 +92,39 @@ def test_full_softmax_mode_and_no_noise():
         _compare(results[g], o, vc, rq)
 
 
+class _PoisonedNet:
+    """FakeNet whose logits rows carry one non-finite value (inf, -inf or nan, at an index that is usually not even a
+    legal move) for positions chosen by a hash of the input: Node._expand then uses uniform priors (mcts.py:147-149)."""
+
+    def __init__(self, seed, sharp):
+        self.net = FakeNet(seed=seed, sharp=sharp)
+
+    def infer_np(self, planes):
+        lg, v = self.net.infer_np(planes)
+        lg = np.array(lg, np.float32, copy=True)
+        for i in range(lg.shape[0]):
+            h = int(np.asarray(planes[i]).sum() * 7919) % 5
+            if h == 0:
+                lg[i, 4671] = np.inf
+            elif h == 1:
+                lg[i, 17] = np.nan
+            elif h == 2:
+                lg[i, 2300] = -np.inf
+        return lg, v
+
+
+def test_nonfinite_logits_give_uniform_priors_as_in_the_reference():
+    G, L, sims = 3, 8, 64
+    e, m = _engine(G, L, sims)
+    net = _PoisonedNet(seed=9, sharp=6.0)
+    for g in range(G):
+        e.search_begin(g, FENS[g], sims, True, 40 + g)
+    results = _run_engine_search(e, net, G)
+    for g in range(G):
+        o, b, vc, pi, rq = _oracle(FENS[g], 40 + g, sims, L, _PoisonedNet(seed=9, sharp=6.0), m, True, True)
+        _compare(results[g], o, vc, rq)
+
+
 def test_tree_reuse_across_moves_matches_oracle():
     """Play 4 plies, each a fresh search on the re-rooted (compacted) subtree; visits accumulate as in the
     reference (TT-reused root, mcts.py:342-371) and Dirichlet re-applies to already-noised priors."""
