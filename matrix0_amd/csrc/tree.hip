@@ -356,9 +356,11 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
                 if (pirr[dd]) { broke = true; break; }
                 if (pkey[dd] == lk) ++cnt;
             }
-            if (!broke)
-                for (int i = hist_len - 1; i >= 0; --i)
-                    if (H[i] == lk) ++cnt;
+            if (!broke)                                   // the game's reversible-move window: one entry per lane
+                for (int i0 = 0; i0 < hist_len; i0 += 64) {
+                    const int i = i0 + lane;
+                    cnt += __popcll(__ballot(i < hist_len && H[i] == lk));
+                }
             if (cnt >= 5) { term = true; tv = c.draw_penalty; }
         }
         int row = -1;
