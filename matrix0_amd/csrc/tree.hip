@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             const double eff = cpuct_at(c, depth);
             double best = -1e9;
             int bi = -1;
-            int b_nch = 0, b_cb = 0, b_n = 0;
+            int b_nch = 0, b_cb = 0, b_n = 0, b_vl = 0;
             double b_q = 0.0;
             Move b_mv = 0;
             for (int i = lane; i < nc; i += 64) {
@@ -314,9 +314,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
                 if (c.no_instant_backtrack && depth >= 1) {
                     if (mv_from(m) == prev_to && mv_to(m) == prev_from) sc -= 0.01;
                 }
-                if (c.virtual_loss_active && c.virtual_loss > 0.0) sc -= (double)A.vl[ci] * c.virtual_loss;
+                const int cvl = c.virtual_loss_active ? A.vl[ci] : 0;
+                if (c.virtual_loss_active && c.virtual_loss > 0.0) sc -= (double)cvl * c.virtual_loss;
                 sc += (u01(seedj, ctrj + (uint64_t)i) - 0.5) * jit;
-                if (sc > best) { best = sc; bi = i; b_nch = c_nch; b_cb = c_cb; b_n = cn; b_q = cq; b_mv = m; }
+                if (sc > best) { best = sc; bi = i; b_nch = c_nch; b_cb = c_cb; b_n = cn; b_q = cq; b_mv = m; b_vl = cvl; }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(best, off);
@@ -334,12 +335,15 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             const bool irr = irreversible(pos, m);
             if (lane == 0) { pkey[depth] = k; pirr[depth] = irr ? 1 : 0; }
             make_move(pos, m);
-            if (lane == 0 && c.virtual_loss_active) A.vl[child] += 1;
+            // the scanned in-flight count + 1 (no second load), and no barrier per level: nothing a level stores
+            // (in-flight count, path, position keys) is read before the walk has ended
+            const int vlw = __shfl(b_vl, wl);
+            if (lane == 0 && c.virtual_loss_active) A.vl[child] = vlw + 1;
             prev_from = mv_from(m); prev_to = mv_to(m);
             node = child; ++depth;
             if (lane == 0) path[depth] = node;
-            __syncthreads();
         }
+        __syncthreads();
         // leaf: is_game_over() (checkmate, insufficient, stalemate, 75-move, fivefold) -> _terminal_value
         const int nlegal = gen_legal_wave(pos, smoves, spseudo, lane);
         const bool chk = in_check(pos);
