@@ -227,6 +227,47 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
 #else
             tap_addr(Ab, tap, abase, afx);
 #endif
+#ifndef PP_KS1
+            // One load / compute phase pair per HALF-TILE (two k16 slices: 14 fragment reads, 20 MFMAs): half the barriers of
+            // the first form (one pair per k16 slice, -DPP_KS1: 457 vs 446 us stand-alone, forward 26.47 vs 26.23 ms).  The
+            // half-tile DMA is issued in the MFMA shadow; its counted wait sits at the end of the load section BEFORE the
+            // half-tile's own (only the previous issue may still be in flight): both groups pass that wait before either
+            // reads the half-tile (group 1's load section ends at the barrier that opens group 0's next one).
+            static_for<0, 2>([&](auto h_) __attribute__((always_inline)) {
+                constexpr int h = decltype(h_)::value;
+                const int yh = y + h;
+                half8 ga0[2], ga1[2], gb[2][NT];
+                static_for<0, 2>([&](auto u_) __attribute__((always_inline)) {
+                    constexpr int u = decltype(u_)::value;
+                    constexpr int j = 2 * h + u;
+                    const char* Wb = W_lds + (yh & 3) * WH_BYTES + wrow_off + 16 * (wfx ^ (u << 1));
+                    ga0[u] = *reinterpret_cast<const half8*>(abase[0] + 16 * (afx[0] ^ (j << 1)));
+                    ga1[u] = *reinterpret_cast<const half8*>(abase[1] + 16 * (afx[1] ^ (j << 1)));
+                    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+                        constexpr int ni = decltype(ni_)::value;
+                        gb[u][ni] = *reinterpret_cast<const half8*>(Wb + ni * 2048);
+                    });
+                });
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                PP_FENCE();
+                PP_BARRIER();
+                PP_FENCE();
+                PP_SETPRIO(1);
+                static_for<0, 2>([&](auto u_) __attribute__((always_inline)) {
+                    constexpr int u = decltype(u_)::value;
+                    static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+                        constexpr int ni = decltype(ni_)::value;
+                        acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga0[u], gb[u][ni], acc[0][ni], 0, 0, 0);
+                        acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga1[u], gb[u][ni], acc[1][ni], 0, 0, 0);
+                        if constexpr (u == 0 && ni == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+                    });
+                });
+                PP_SETPRIO(0);
+                PP_FENCE();
+                PP_BARRIER();
+                PP_FENCE();
+            });
+#else
             static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_)::value;      // 16-deep k slice of the K-tile
                 constexpr int h = j >> 1;
@@ -291,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                 PP_BARRIER();
                 PP_FENCE();
             });
+#endif
             y += 2;
 #ifdef PP_TRACE
             ++kt;
