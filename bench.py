@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--ssl", action="store_true", help="run the 5 SSL heads in every evaluation (configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
+                         "+3..4 %% games/s, but per-launch kernel timings then include the other stream's kernels, so the "
+                         "roofline of the default run is taken with 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +158,14 @@ def main():
     cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
                                      first_game_index=m0dist.shard_games(args.games * world, rank, world)[0], leaves_per_step=args.leaves,
                                      virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
-    e = eng.SelfplayEngine(be, cfg)
+    if args.streams > 1:
+        made = [be]
+        e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
+                             cfg_dict, streams=args.streams, concurrent_games=args.games, total_games=0,
+                             first_game_index=m0dist.shard_games(args.games * world, rank, world)[0], leaves_per_step=args.leaves,
+                             virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
+    else:
+        e = eng.SelfplayEngine(be, cfg)
 
     def sync():
         torch.cuda.synchronize()
@@ -213,7 +224,8 @@ def main():
             "config": {"workload": f"{args.games} concurrent games per GPU x {args.gpus} GPU, {args.sims} sims/move, "
                                    f"R24-320 (57.56M params, {flops_eval / 1e9:.4f} GFLOP/eval) fp16 MFMA, {args.leaves} leaves/tree/step"
                                    + (", 5 SSL heads in forward" if args.ssl else ""),
-                       "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"},
+                       "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"
+                       + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "time_split_ms_per_step": {"net": ms_net / args.gpus / max(1, args.steps), "tree": ms_tree / args.gpus / max(1, args.steps),

@@ -24,7 +24,7 @@ import numpy as np
 from . import encoding
 from .backend import M0Backend
 from .data_writer import ReplayShardWriter, SelfplayShardWriter
-from .engine import SelfplayEngine, selfplay_cfg_from_dict
+from .engine import SelfplayEngine, SelfplayPool, selfplay_cfg_from_dict
 from .weights import random_state_dict
 
 START_W = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
@@ -48,11 +48,15 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     eng_cfg = dict(cfg_dict.get("engine", {}) or {})
     device_index = int(eng_cfg.get("device_index", 0))
     model_cfg = dict(cfg_dict["model"])
+    def make_backend():
+        if ckpt_path and os.path.exists(ckpt_path):
+            return M0Backend.from_checkpoint(model_cfg, ckpt_path, device_index)
+        return M0Backend.from_state_dict(model_cfg, random_state_dict(model_cfg, seed=base_seed + proc_id), device_index)
+
+    backend = make_backend()
     if ckpt_path and os.path.exists(ckpt_path):
-        backend = M0Backend.from_checkpoint(model_cfg, ckpt_path, device_index)
         logger.info("Loaded checkpoint from %s", ckpt_path)
     else:
-        backend = M0Backend.from_state_dict(model_cfg, random_state_dict(model_cfg, seed=base_seed + proc_id), device_index)
         logger.info("No checkpoint provided, using untrained model")
     force_vfw = bool((cfg_dict.get("mcts", {}) or {}).get("value_from_white", False))
     value_from_white = force_vfw or detect_value_from_white(backend)
@@ -61,12 +65,20 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     # SSL targets are generated whenever the model has SSL enabled (selfplay/internal.py:312-318)
     ssl_tasks = list(model_cfg.get("ssl_tasks", [])) if model_cfg.get("self_supervised", False) else []
     concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
-    scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
-                                  first_game_index=0, seed=base_seed + proc_id,
-                                  leaves_per_step=eng_cfg.get("leaves_per_step", 16),
-                                  virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
-                                  ssl_targets=bool(ssl_tasks))
-    engine = SelfplayEngine(backend, scfg)
+    eng_kw = dict(seed=base_seed + proc_id, leaves_per_step=eng_cfg.get("leaves_per_step", 16),
+                  virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
+                  ssl_targets=bool(ssl_tasks))
+    # engine.streams > 1: that many independent engines (own network instance and HIP stream each) share the games and
+    # step concurrently -- same games, same records per game index, +3..4 % throughput at 2 (engine.SelfplayPool)
+    streams = int(eng_cfg.get("streams", 1))
+    if streams > 1:
+        first = [backend]
+        engine = SelfplayPool(lambda: first.pop() if first else make_backend(), cfg2, streams=streams,
+                              concurrent_games=min(concurrent, max(1, games)), total_games=games, first_game_index=0, **eng_kw)
+    else:
+        scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
+                                      first_game_index=0, **eng_kw)
+        engine = SelfplayEngine(backend, scfg)
     # engine.replay_shards: emit replay-buffer shards directly (ReplayShardWriter: what the orchestrator's
     # compact_selfplay_to_replay would make of the per-game files) instead of one NPZ per game
     direct_replay = bool(eng_cfg.get("replay_shards", False))

@@ -96,6 +96,40 @@ def test_selfplay_is_deterministic_for_a_seed():
     assert outs[0] == outs[1]
 
 
+def _play_all(e):
+    games = {}
+    for _ in range(6000):
+        e.step(8)
+        while (r := e.poll()) is not None:
+            games[r["game_index"]] = r
+        if not e.running():
+            break
+    return games
+
+
+def test_two_engines_on_two_streams_play_the_same_games():
+    """engine.SelfplayPool: the games of a GPU shared by two independent engines (own network instance and HIP stream),
+    stepped concurrently from two host threads.  A game depends only on (seed, game index) and the network is
+    batch-invariant, so every record must be bit-identical to the single-engine run."""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    # a 320-channel network: the big-tile kernels are bitwise batch-invariant (test_net_gpu), the 32-channel test network's
+    # small-tile kernels are only so to 1e-7, which is enough to change a visit count somewhere in a game
+    net = dict(NET, channels=320, blocks=3, attention_heads=20, policy_factor_rank=128)
+    sd = net_ref.random_state_dict(net, seed=2)
+    one = eng.SelfplayEngine(M0Backend.from_state_dict(net, sd), eng.selfplay_cfg_from_dict(CFG, concurrent_games=6, total_games=10))
+    ref_games = _play_all(one)
+    pool = eng.SelfplayPool(lambda: M0Backend.from_state_dict(net, sd), CFG, streams=2, concurrent_games=6, total_games=10)
+    games = _play_all(pool)
+    st = pool.stats()
+    pool.close()
+    assert sorted(games) == sorted(ref_games) == list(range(10)) and st["games_finished"] == 10
+    for i in range(10):
+        a, b = ref_games[i], games[i]
+        assert a["played"] == b["played"] and a["result"] == b["result"] and a["moves"] == b["moves"], i
+        assert np.array_equal(a["pi"], b["pi"]) and np.array_equal(a["z"], b["z"]) and np.array_equal(a["s"], b["s"]), i
+
+
 def test_drop_in_worker_writes_shards_and_queue_messages(tmp_path):
     """selfplay_worker(proc_id, cfg_dict, ckpt_path, games, q): same call as the reference (internal.py:94-95);
     checks the queue message schema (internal.py:665-679) and the NPZ/SQLite contract (internal.py:628-653)."""
