@@ -27,6 +27,7 @@ Deviation switches (reference default in brackets):
 from __future__ import annotations
 
 import math
+from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -202,6 +203,7 @@ class MCTS:
         self.noise = Stream(derive_seed(seed, game, PURPOSE_NOISE))
         self.dirichlet = Stream(derive_seed(seed, game, PURPOSE_DIRICHLET))
         self.tt: Dict[bytes, Node] = {}
+        self.nn_cache: "OrderedDict[bytes, tuple]" = OrderedDict()
         self.evals = 0
         self._last_sims_run = 0
         self._last_root = None
@@ -351,10 +353,19 @@ class MCTS:
             self.expand(root, board, logits)
             if cfg.use_tt:
                 self.tt[key] = root
-        elif root.expanded and root.n > 0:
-            pass          # reference re-infers only to refresh `v`, which is unused once root.n > 0
         else:
-            _, v = self._infer_one(board)
+            # mcts.py:359-371: a root found in the table is re-evaluated unless (logits, v) of this position sit in
+            # the 10 000-entry nn_cache (mcts.py:44-59), which is written here and nowhere else
+            cached = self.nn_cache.get(key)
+            if cached is None:
+                logits, v = self._infer_one(board)
+                self.nn_cache[key] = (logits, v)
+                self.nn_cache.move_to_end(key)
+                if len(self.nn_cache) > 10000:
+                    self.nn_cache.popitem(last=False)
+            else:
+                self.nn_cache.move_to_end(key)
+                _, v = cached
         if cfg.dirichlet_plies is None or ply is None or ply < int(cfg.dirichlet_plies):
             self.add_dirichlet(root)
         sims = num_simulations if num_simulations is not None else cfg.num_simulations
