@@ -76,6 +76,8 @@ typedef struct m0_net m0_net;
 
 const char* m0_last_error(void);
 const char* m0_version(void);
+/* hipGetDeviceCount: MI355X visible to this process (0 when there is none; never an error). */
+int m0_device_count(void);
 
 /* ---- network (seam 1) ---- */
 m0_net* m0_net_create(const m0_net_cfg* cfg, int hip_device);
@@ -158,6 +160,15 @@ typedef struct m0_selfplay_cfg {
     int arena_mode;               /* set by m0_arena_create */
     double arena_temp;            /* move choice: softmax(log(visits+1e-8)/temp) for the first arena_temp_plies plies ... */
     int arena_temp_plies;         /* ... then (or with temp <= 1e-3) the most visited move, first maximum in move order */
+    /* compatibility switches (reference behaviours the default engine deviates from; 0 = engine default) */
+    int fresh_tree_per_move;      /* 1 = every move starts from a brand-new root (what the reference does with MCTS._tt_get
+                                     patched out, the mode tests/golden/ref_worker_*.npz were played in); 0 = keep the played
+                                     child's subtree */
+    int tt_merge;                 /* 1 = transposition merging inside a search as mcts.py:919 + :1330-1346 (search graph is a DAG) */
+    int raw_legal_priors;         /* 1 = Node._expand_with_legal_priors (mcts.py:227-256): non-root priors = legal logits / their sum */
+    int max_children;             /* MCTS._prune_children (mcts.py:806-826): keep the top-K children by prior; 0 = off */
+    double min_child_prior;       /* ... after dropping children with prior < this; 0 = off */
+    int root_reinfer;             /* 1 = re-evaluate a reused root as mcts.py:359-371 does (nn_cache of 10 000 positions) */
 } m0_selfplay_cfg;
 
 typedef struct m0_selfplay m0_selfplay;
@@ -197,6 +208,16 @@ int m0_selfplay_poll(m0_selfplay* sp, m0_game_record* out);
 void m0_game_record_free(m0_game_record* rec);
 /* 1 while games remain to be played or are in flight. */
 int m0_selfplay_running(m0_selfplay* sp);
+/* Opening book (selfplay/internal.py:34-69 load_opening_book / get_opening_position): every new game starts from one of
+ * these positions, chosen with the game's own stream as random.choice(OPENING_BOOK) would; n = 0 clears the book
+ * (games start from the initial position).  Call before the first step. */
+int m0_selfplay_set_openings(m0_selfplay* sp, const char* const* fens, int n);
+/* The self-play step split at the network, for an external evaluator behind the reference's infer_np seam (net may be
+ * NULL): ext_select runs select for all resident games and returns the leaf planes f32 [rows,19,8,8]; ext_expand takes
+ * logits f32 [rows,4672] and values f32 [rows], expands / backs up, and does the host part of the step (moves, game
+ * ends, restarts) exactly as m0_selfplay_step does.  Parity tests play whole games against golden files this way. */
+int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_rows);
+int m0_selfplay_ext_expand(m0_selfplay* sp, const float* logits, const float* values, int rows);
 
 /* Evaluation match between two networks (azchess/arena.py:59-126 _arena_run_one_game, :305 play_match): game i is played
  * with net_a as White when i is even.  Every search of a game is evaluated by the network of the side to move; each

@@ -83,6 +83,10 @@ def lib():
     return L
 
 
+def device_count() -> int:
+    return int(lib().m0_device_count())
+
+
 def last_error() -> str:
     return (lib().m0_last_error() or b"").decode("utf-8", "replace")
 

@@ -33,7 +33,12 @@ int m0_net_device(m0_net* n) { return n ? n->device : 0; }
 extern "C" {
 
 const char* m0_last_error(void) { return g_m0_last_error.c_str(); }
-const char* m0_version(void) { return "m0engine 0.1 (gfx950)"; }
+const char* m0_version(void) { return "m0engine 0.2 (gfx950)"; }
+int m0_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 
 m0_net* m0_net_create(const m0_net_cfg* cfg, int hip_device) {
     if (!cfg) { m0_set_error("cfg is null"); return nullptr; }

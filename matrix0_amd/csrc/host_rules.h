@@ -190,11 +190,19 @@ inline int sample_move_index(const int32_t* visits, int n, double temperature, d
     if (!(s > 0.f) || isnan(s)) return uniform_pick();
     double cum = 0.0;
     std::vector<double> cdf(n);
-    for (int i = 0; i < n; ++i) { d[i] = d[i] / s; cum += (double)d[i]; cdf[i] = cum; }
+    bool anynan = false;
+    for (int i = 0; i < n; ++i) { d[i] = d[i] / s; anynan = anynan || isnan(d[i]); cum += (double)d[i]; cdf[i] = cum; }
+    if (anynan) return uniform_pick();            // internal.py:727-732: overflowed powers (inf / inf)
     const double last = cdf[n - 1];
     for (int i = 0; i < n; ++i)
         if (cdf[i] / last > u) return i;
     return n - 1;
+}
+// whether sample_move_from_counts consumes a random draw: every branch but the arg-max one (internal.py:706-708)
+inline bool sample_move_draws(const int32_t* visits, int n, double temperature) {
+    bool allzero = true;
+    for (int i = 0; i < n; ++i) if (visits[i] != 0) allzero = false;
+    return allzero || !(temperature < 1e-3);
 }
 
 // arena move choice (arena.py:73-86, 106): float32 logits = log(visits + 1e-8) / max(temp, 1e-3), softmax, then

@@ -85,6 +85,8 @@ struct m0_selfplay {
     std::vector<int> prev_done;           // per slot: simulations already credited to stats.sims
     int last_rows = 0;
     int rows2[2] = {0, 0};                // rows of the last select per network
+    std::vector<Pos> book;                // opening positions (m0_selfplay_set_openings)
+    bool ext_pending = false;             // ext_select done, ext_expand outstanding
 };
 
 namespace {
@@ -156,6 +158,11 @@ void start_game(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::vecto
     sp->stats.games_started++;
     parse_fen("rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1", hgm.pos);
     hgm.rng = HStream(derive_seed(sp->cfg.seed, hgm.game_index, PURPOSE_GAME));
+    if (!sp->book.empty()) {               // get_opening_position (internal.py:65-69): random.choice(OPENING_BOOK)
+        size_t k = (size_t)(hgm.rng.next() * (double)sp->book.size());
+        if (k >= sp->book.size()) k = sp->book.size() - 1;
+        hgm.pos = sp->book[k];
+    }
     hgm.t0 = now_ms();
     hgm.a_is_white = (hgm.game_index % 2) == 0;               // arena.py:66
     seed_game_dev(sp->hg[slot], sp->cfg.seed, hgm.game_index);
@@ -191,8 +198,11 @@ void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv
         child_slot = -1;                                           // a fresh tree per move (see m0_arena_create)
         sp->hg[slot].net_id = ((hgm.pos.turn == WHITE) == hgm.a_is_white) ? 0 : 1;
     }
-    int sims = playout_cap(c.num_simulations, c.playout_random_frac, hgm.rng.next());
+    // mcts.py:378-387 draws random.randint only when the cap is configured
+    const bool cap_draws = c.playout_random_frac > 0.0 && c.num_simulations > 0;
+    int sims = playout_cap(c.num_simulations, c.playout_random_frac, cap_draws ? hgm.rng.next() : 0.0);
     hgm.cur_sims = sims;
+    if (c.fresh_tree_per_move) child_slot = -1;
     const bool dir = c.dirichlet_plies < 0 || hgm.nstates < c.dirichlet_plies;
     arm_search(sp, slot, hgm.pos, hgm.win, sims, dir, child_slot < 0);
     adv_ids.push_back(slot);
@@ -299,7 +309,7 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
         const bool sampling = c.arena_temp > 1e-3 && hgm.nstates < c.arena_temp_plies;
         pick = arena_choose_move(visits.data(), k, c.arena_temp, hgm.nstates, c.arena_temp_plies, sampling ? hgm.rng.next() : 0.0);
     } else {
-        pick = sample_move_index(visits.data(), k, temp, hgm.rng.next());
+        pick = sample_move_index(visits.data(), k, temp, sample_move_draws(visits.data(), k, temp) ? hgm.rng.next() : 0.0);
     }
     const Move mv = R.child_mv[pick];
     hgm.search_values.push_back((float)root_q);
@@ -339,6 +349,8 @@ int apply_advances(m0_selfplay* sp, std::vector<int>& ids, std::vector<int>& slo
     return 0;
 }
 
+int step_back(m0_selfplay* sp, int rows, double t0, std::string& err);
+
 int one_step(m0_selfplay* sp, std::string& err) {
     const double t0 = now_ms();
     (void)hipEventRecord(sp->ev0, sp->stream);
@@ -360,6 +372,11 @@ int one_step(m0_selfplay* sp, std::string& err) {
         if (rc != M0_OK) return rc;
         rows += sp->rows2[1];
     }
+    return step_back(sp, rows, t0, err);
+}
+
+// second half of a step: expand / backup on the device, then the host part (finished searches -> moves, game ends, restarts)
+int step_back(m0_selfplay* sp, int rows, double t0, std::string& err) {
     (void)hipEventRecord(sp->ev2, sp->stream);
     if (launch_expand(sp->d, sp->tc, sp->stream) != hipSuccess) { err = "expand launch failed"; return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev3, sp->stream);
@@ -547,21 +564,89 @@ void m0_selfplay_destroy(m0_selfplay* sp) {
     delete sp;
 }
 
+// lazily start the first games
+static int start_first_games(m0_selfplay* sp) {
+    if (sp->stats.games_started != 0) return M0_OK;
+    std::vector<int> ids, slots;
+    if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+    for (int s = 0; s < sp->G; ++s) {
+        if (sp->cfg.total_games > 0 && sp->next_game >= sp->cfg.total_games) break;
+        start_game(sp, s, ids, slots);
+    }
+    if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
+    int act = 0;
+    for (int s = 0; s < sp->G; ++s) act += sp->games[s].in_use ? 1 : 0;
+    sp->stats.active_games = act;
+    return M0_OK;
+}
+
+int m0_selfplay_set_openings(m0_selfplay* sp, const char* const* fens, int n) {
+    if (!sp || n < 0 || (n > 0 && !fens)) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp->stats.games_started != 0) { m0_set_error("set the opening book before the first step"); return M0_ERR_STATE; }
+    std::vector<Pos> book(n);
+    for (int i = 0; i < n; ++i)
+        if (!fens[i] || parse_fen(fens[i], book[i]) != 0) { m0_set_error(std::string("bad FEN at index ") + std::to_string(i)); return M0_ERR_INVALID; }
+    sp->book.swap(book);
+    return M0_OK;
+}
+
+int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_rows) {
+    if (!sp || !rows) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    if (sp->cfg.arena_mode) { m0_set_error("the external-evaluator step serves self-play engines only"); return M0_ERR_STATE; }
+    if (sp->ext_pending) { m0_set_error("m0_selfplay_ext_expand outstanding"); return M0_ERR_STATE; }
+    int rc = start_first_games(sp);
+    if (rc != M0_OK) return rc;
+    int r = 0;
+    if (run_select(sp, &r) != 0) { m0_set_error(std::string("select failed: ") + hipGetErrorString(hipGetLastError())); return M0_ERR_HIP; }
+    if (r > sp->rows_max) { m0_set_error("row counter overflow"); return M0_ERR_STATE; }
+    *rows = r;
+    sp->last_rows = r;
+    sp->ext_pending = true;
+    if (r > 0) {
+        if (!planes || r > max_rows) { m0_set_error("planes buffer too small"); return M0_ERR_INVALID; }
+        if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
+        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * sp->L, hipMemcpyDeviceToHost);
+        for (int g = 0; g < sp->G; ++g) {
+            if (!sp->hg[g].active) continue;
+            for (int s = 0; s < sp->hg[g].nsamples; ++s) {
+                const Sample& smp = sp->hsamples[(size_t)g * sp->L + s];
+                if ((smp.kind == 1 || smp.kind == 2) && smp.row >= 0 && smp.row < r)
+                    encode_planes_f32(smp.pos, planes + (size_t)smp.row * 19 * 64);
+            }
+        }
+    }
+    return M0_OK;
+}
+
+int m0_selfplay_ext_expand(m0_selfplay* sp, const float* logits, const float* values, int rows) {
+    if (!sp) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    if (!sp->ext_pending) { m0_set_error("no m0_selfplay_ext_select outstanding"); return M0_ERR_STATE; }
+    if (rows != sp->last_rows) { m0_set_error("rows does not match the last select"); return M0_ERR_INVALID; }
+    if (rows > 0) {
+        if (!logits || !values) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+        (void)hipMemcpyAsync(sp->logits_dev, logits, (size_t)rows * 4672 * 4, hipMemcpyHostToDevice, sp->stream);
+        (void)hipMemcpyAsync(sp->values_dev, values, (size_t)rows * 4, hipMemcpyHostToDevice, sp->stream);
+    }
+    sp->ext_pending = false;
+    std::string err;
+    (void)hipEventRecord(sp->ev0, sp->stream); (void)hipEventRecord(sp->ev1, sp->stream);
+    int rc = step_back(sp, rows, now_ms(), err);
+    if (rc != M0_OK) m0_set_error(err);
+    return rc;
+}
+
 int m0_selfplay_step(m0_selfplay* sp, int steps) {
     if (!sp) { m0_set_error("sp is null"); return M0_ERR_INVALID; }
     std::lock_guard<std::mutex> lk(sp->mu);
     (void)hipSetDevice(sp->device);
     std::string err;
-    // lazily start the first games
-    if (sp->stats.games_started == 0) {
-        std::vector<int> ids, slots;
-        if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
-        for (int s = 0; s < sp->G; ++s) {
-            if (sp->cfg.total_games > 0 && sp->next_game >= sp->cfg.total_games) break;
-            start_game(sp, s, ids, slots);
-        }
-        if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
-    }
+    if (sp->ext_pending) { m0_set_error("m0_selfplay_ext_expand outstanding"); return M0_ERR_STATE; }
+    { int rc0 = start_first_games(sp); if (rc0 != M0_OK) return rc0; }
     for (int i = 0; i < steps; ++i) {
         if (sp->stats.active_games == 0 && sp->stats.steps > 0) break;
         int rc = one_step(sp, err);

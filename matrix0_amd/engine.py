@@ -29,6 +29,8 @@ class SelfplayCfg(C.Structure):
         ("concurrent_games", c_int), ("total_games", c_int), ("first_game_index", c_int), ("arena_nodes", c_int),
         ("seed", c_u64), ("virtual_loss_active", c_int), ("ssl_in_forward", c_int), ("ssl_targets", c_int), ("record_games", c_int),
         ("arena_mode", c_int), ("arena_temp", c_double), ("arena_temp_plies", c_int),
+        ("fresh_tree_per_move", c_int), ("tt_merge", c_int), ("raw_legal_priors", c_int), ("max_children", c_int),
+        ("min_child_prior", c_double), ("root_reinfer", c_int),
     ]
 
 
@@ -68,6 +70,9 @@ def _bind():
     L.m0_game_record_free.argtypes = [C.POINTER(GameRecord)]
     L.m0_game_record_free.restype = None
     L.m0_selfplay_running.argtypes = [C.c_void_p]
+    L.m0_selfplay_set_openings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), c_int]
+    L.m0_selfplay_ext_select.argtypes = [C.c_void_p, C.POINTER(c_int), C.c_void_p, c_int]
+    L.m0_selfplay_ext_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int]
     L.m0_search_begin.argtypes = [C.c_void_p, c_int, C.c_char_p, c_int, c_int, c_int]
     L.m0_search_select.argtypes = [C.c_void_p, C.POINTER(c_int), C.c_void_p, c_int]
     L.m0_search_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int]
@@ -92,7 +97,8 @@ def _bind():
 def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int = 0, first_game_index: int = 0,
                            seed: Optional[int] = None, leaves_per_step: Optional[int] = None,
                            virtual_loss_active: bool = True, ssl_in_forward: bool = False,
-                           record_games: bool = True, arena_nodes: int = 0, ssl_targets: bool = False) -> SelfplayCfg:
+                           record_games: bool = True, arena_nodes: int = 0, ssl_targets: bool = False,
+                           compat: Optional[dict] = None) -> SelfplayCfg:
     """Merge config.yaml's `mcts`, `selfplay` and draw sections exactly as selfplay_worker does
     (azchess/selfplay/internal.py:192-199, 269-304) into the engine's C struct.  MCTSConfig
     defaults are the dataclass defaults of azchess/mcts.py:61-107."""
@@ -159,6 +165,16 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     c.ssl_in_forward = int(bool(ssl_in_forward))
     c.ssl_targets = int(bool(ssl_targets))
     c.record_games = int(bool(record_games))
+    # reference behaviours the engine deviates from by default: `engine.compat` in config.yaml, or the `compat` argument
+    cp = dict(((cfg.get("engine", {}) or {}).get("compat", {}) or {}))
+    cp.update(compat or {})
+    unknown = set(cp) - {"fresh_tree_per_move", "tt_merge", "raw_legal_priors", "root_reinfer"}
+    if unknown:
+        raise ValueError(f"unknown engine.compat keys: {sorted(unknown)}")
+    c.fresh_tree_per_move = int(bool(cp.get("fresh_tree_per_move", False)))
+    c.tt_merge = int(bool(cp.get("tt_merge", False)))
+    c.raw_legal_priors = int(bool(cp.get("raw_legal_priors", False)))
+    c.root_reinfer = int(bool(cp.get("root_reinfer", False)))
     return c
 
 
@@ -225,6 +241,25 @@ class SelfplayEngine:
         finally:
             self._L.m0_game_record_free(C.byref(r))
         return out
+
+    def set_openings(self, fens: List[str]) -> None:
+        """Opening book positions (selfplay/internal.py:34-69); call before the first step."""
+        arr = (C.c_char_p * max(1, len(fens)))(*[f.encode() for f in fens])
+        _lib.check(self._L.m0_selfplay_set_openings(self._h, arr, len(fens)), "m0_selfplay_set_openings")
+
+    def ext_select(self) -> np.ndarray:
+        """First half of a self-play step for an external evaluator: the leaf planes f32 [rows,19,8,8]."""
+        rows = c_int(0)
+        cap = self.cfg.concurrent_games * self.cfg.inference_batch_size
+        planes = np.zeros((cap, 19, 8, 8), dtype=np.float32)
+        _lib.check(self._L.m0_selfplay_ext_select(self._h, C.byref(rows), planes.ctypes.data_as(C.c_void_p), cap), "m0_selfplay_ext_select")
+        return planes[: rows.value]
+
+    def ext_expand(self, logits: np.ndarray, values: np.ndarray) -> None:
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        vv = np.ascontiguousarray(values, dtype=np.float32)
+        _lib.check(self._L.m0_selfplay_ext_expand(self._h, lg.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p),
+                                                  int(lg.shape[0])), "m0_selfplay_ext_expand")
 
     # ---- split-step search ----
     def search_begin(self, g: int, fen: str, sims: int, dirichlet: bool, game_uid: int) -> None:

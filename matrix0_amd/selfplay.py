@@ -9,7 +9,13 @@ by orchestrator.py:494 and selfplay/__main__.py:68).  Same config dict, same que
 Instead of one game at a time with a Python MCTS, the games of this worker run concurrently on one MI355X inside
 libm0engine.so; `shared_memory_resource` (the reference's inference-server handle) is accepted and ignored: leaf
 batching happens in the engine.  New keys live under an `engine:` section only:
-    engine: {device_index: int, concurrent_games: int, leaves_per_step: int, virtual_loss_active: bool}
+    engine: {device_index: int, concurrent_games: int, leaves_per_step: int, virtual_loss_active: bool,
+             first_game_index: int, compat: {fresh_tree_per_move, tt_merge, raw_legal_priors, root_reinfer}}
+
+The orchestrator hands the SAME cfg_dict to every worker (orchestrator.py:490-496), so what tells workers apart is
+proc_id alone: worker i runs on GPU  i % (visible MI355X)  and plays the global game indices [i*games, (i+1)*games) --
+the random streams are keyed by (seed, game index), so a game is the same game whichever worker or GPU plays it
+(worker_placement below; `engine.device_index` / `engine.first_game_index` override).
 """
 from __future__ import annotations
 
@@ -39,14 +45,43 @@ def detect_value_from_white(backend: M0Backend) -> bool:
     return not (abs(v2 + v1) < abs(v2 - v1))
 
 
+def worker_placement(proc_id: int, games: int, eng_cfg: dict, n_devices: int):
+    """(device index, first global game index) of worker `proc_id`: workers spread round-robin over the visible GPUs and
+    own disjoint blocks of game indices."""
+    dev = eng_cfg.get("device_index")
+    dev = int(dev) if dev is not None else (int(proc_id) % max(1, int(n_devices)))
+    first = eng_cfg.get("first_game_index")
+    first = int(first) if first is not None else int(proc_id) * max(0, int(games))
+    return dev, first
+
+
+def check_unsupported_sections(cfg_dict: dict) -> None:
+    """Worker-side features of the reference that this engine does not implement must not be dropped silently."""
+    op = cfg_dict.get("openings", {}) or {}
+    if op.get("polyglot") and int(op.get("max_plies", 0) or 0) > 0:
+        raise NotImplementedError("openings.polyglot (selfplay/internal.py:71-91, 328-333: python-chess polyglot reader) is not "
+                                  "implemented by the MI355X engine; use selfplay.opening_random_plies or engine.opening_fens")
+    tb = cfg_dict.get("tablebases", {}) or {}
+    if tb.get("enabled", False):
+        raise NotImplementedError("tablebases.enabled (selfplay/internal.py:250-260, 560-581: Syzygy probing through python-chess) "
+                                  "is not implemented by the MI355X engine; set tablebases.enabled: false")
+    if (cfg_dict.get("selfplay", {}) or {}).get("book_path") and not (cfg_dict.get("engine", {}) or {}).get("opening_fens"):
+        raise NotImplementedError("selfplay.book_path is a PGN read with python-chess (selfplay/internal.py:34-63); give the engine "
+                                  "the book as FEN strings in engine.opening_fens instead")
+
+
 def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], games: int, q=None,
                     shared_memory_resource: Optional[Dict[str, Any]] = None) -> None:
     logger = logging.getLogger(f"selfplay_worker_{proc_id}")
+    if int(games) <= 0:                      # `for g in range(games)` (internal.py:326): nothing to play, return at once
+        return
+    check_unsupported_sections(cfg_dict)
     base_seed = int(cfg_dict.get("seed", 1234))
     random.seed(base_seed + proc_id)
     np.random.seed(base_seed + proc_id)
     eng_cfg = dict(cfg_dict.get("engine", {}) or {})
-    device_index = int(eng_cfg.get("device_index", 0))
+    from . import _lib
+    device_index, first_game_index = worker_placement(proc_id, games, eng_cfg, _lib.device_count())
     model_cfg = dict(cfg_dict["model"])
     def make_backend():
         if ckpt_path and os.path.exists(ckpt_path):
@@ -65,20 +100,24 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     # SSL targets are generated whenever the model has SSL enabled (selfplay/internal.py:312-318)
     ssl_tasks = list(model_cfg.get("ssl_tasks", [])) if model_cfg.get("self_supervised", False) else []
     concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
-    eng_kw = dict(seed=base_seed + proc_id, leaves_per_step=eng_cfg.get("leaves_per_step", 16),
+    eng_kw = dict(seed=base_seed, leaves_per_step=eng_cfg.get("leaves_per_step", 16),
                   virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
-                  ssl_targets=bool(ssl_tasks))
+                  ssl_targets=bool(ssl_tasks), arena_nodes=int(eng_cfg.get("arena_nodes", 0) or 0))
     # engine.streams > 1: that many independent engines (own network instance and HIP stream each) share the games and
     # step concurrently -- same games, same records per game index, +3..4 % throughput at 2 (engine.SelfplayPool)
     streams = int(eng_cfg.get("streams", 1))
     if streams > 1:
         first = [backend]
         engine = SelfplayPool(lambda: first.pop() if first else make_backend(), cfg2, streams=streams,
-                              concurrent_games=min(concurrent, max(1, games)), total_games=games, first_game_index=0, **eng_kw)
+                              concurrent_games=min(concurrent, max(1, games)), total_games=games,
+                              first_game_index=first_game_index, **eng_kw)
     else:
         scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
-                                      first_game_index=0, **eng_kw)
+                                      first_game_index=first_game_index, **eng_kw)
         engine = SelfplayEngine(backend, scfg)
+    if eng_cfg.get("opening_fens"):
+        for e in (engine.engines if hasattr(engine, "engines") else [engine]):
+            e.set_openings(list(eng_cfg["opening_fens"]))
     # engine.replay_shards: emit replay-buffer shards directly (ReplayShardWriter: what the orchestrator's
     # compact_selfplay_to_replay would make of the per-game files) instead of one NPZ per game
     direct_replay = bool(eng_cfg.get("replay_shards", False))
@@ -89,6 +128,7 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
         writer = SelfplayShardWriter(base_dir=cfg_dict.get("data_dir", "data"))
     last_hb = time.perf_counter()
     done = 0
+    overflows = 0
     try:
         while engine.running():
             engine.step(int(eng_cfg.get("steps_per_poll", 8)))
@@ -122,8 +162,12 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                            "draw": bool(z == 0.0), "avg_policy_entropy": rec["avg_policy_entropy"],
                            "avg_ms_per_move": rec["secs"] * 1000.0 / max(1, T), "avg_sims": rec["avg_sims"]})
             now = time.perf_counter()
+            st = engine.stats()
+            if int(st["arena_overflows"]) > overflows:             # truncated searches (mcts.py:435-463 raises there)
+                overflows = int(st["arena_overflows"])
+                logger.warning("worker %d: %d searches hit the node-arena limit or ended without visits; raise engine.arena_nodes",
+                               proc_id, overflows)
             if q is not None and now - last_hb >= 2.0:             # internal.py:542-556
-                st = engine.stats()
                 q.put({"type": "heartbeat", "proc": proc_id, "game": done, "moves": int(st["plies"]),
                        "avg_sims": float(st["sims"]) / max(1.0, float(st["plies"])), "resigned": False,
                        "avg_policy_entropy": 0.0})

@@ -430,14 +430,23 @@ def sample_move_index(visits: List[int], temperature: float, u: float) -> int:
         return min(len(visits) - 1, int(u * len(visits)))
     if temperature < 1e-3:
         return int(np.argmax(v))
-    d = v ** (1.0 / temperature)
-    s = d.sum()
-    if s <= 0 or np.isnan(s):
+    with np.errstate(over="ignore", invalid="ignore"):
+        d = v ** (1.0 / temperature)
+        s = d.sum()
+        if s <= 0 or np.isnan(s):
+            return min(len(visits) - 1, int(u * len(visits)))
+        d = d / s
+    if np.any(np.isnan(d)):                        # internal.py:727-732 (overflowed powers: inf / inf)
         return min(len(visits) - 1, int(u * len(visits)))
-    d = d / s
     cdf = np.cumsum(d.astype(np.float64))
     cdf /= cdf[-1]
     return int(min(len(visits) - 1, np.searchsorted(cdf, u, side="right")))
+
+
+def sample_move_draws(visits: List[int], temperature: float) -> bool:
+    """Whether sample_move_from_counts consumes a random draw: every branch but the deterministic arg-max
+    (internal.py:706-708) calls np.random.choice."""
+    return all(x == 0 for x in visits) or not (temperature < 1e-3)
 
 
 def policy_entropy(pi: np.ndarray) -> float:

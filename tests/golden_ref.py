@@ -18,9 +18,11 @@ def load_npz(name):
 
 
 def uci(code):
+    if code == 0:
+        return "0000"                                  # chess.Move.null()
     f, t, p = code & 63, (code >> 6) & 63, (code >> 12) & 7
     s = "abcdefgh"[f & 7] + str((f >> 3) + 1) + "abcdefgh"[t & 7] + str((t >> 3) + 1)
-    return s + (" nbrq"[p] if p else "")
+    return s + ("  nbrq"[p] if p else "")          # p = python-chess piece type (KNIGHT=2 .. QUEEN=5)
 
 
 def planes_from_bits(bits17x8, counters2):

@@ -1,0 +1,104 @@
+"""The HIP search kernels compared DIRECTLY with traces of the real reference code (tests/golden/ref_mcts.json.gz, produced by
+running /root/reference/azchess/mcts.py: see tools/gen_golden_mcts.py) -- no oracle in between.  Same counter streams, same
+bit-reproducible evaluator (tests/hash_net.py) fed through the split-step C-ABI.  The reference has no virtual loss and, in
+these cases, its transposition table patched out (tree-only), so the engine runs with virtual_loss_active=0.
+
+Integer results (move order, policy indices, visit counts, simulations) must be identical; float32 priors within 1e-6
+(the tolerance of the reference's own tests/test_mcts_logits.py); float64 q / root value within 1e-9."""
+import numpy as np
+import pytest
+
+from tests.golden_ref import load_json, uci
+from tests.hash_net import HashNet
+
+pytestmark = pytest.mark.gpu
+G = load_json("ref_mcts.json.gz")
+FENS, BASE = G["fens"], G["base_mcts"]
+
+
+def _engine(mcts, seed, L, compat=None):
+    from matrix0_amd import engine as eng
+    cfg = eng.selfplay_cfg_from_dict({"seed": seed, "mcts": dict(mcts, inference_batch_size=L), "selfplay": {"num_simulations": 1}},
+                                     concurrent_games=1, virtual_loss_active=False, compat=compat)
+    return eng.SelfplayEngine(None, cfg)
+
+
+def _search(e, net):
+    for _ in range(100000):
+        planes = e.search_select()
+        lg, v = net.infer_np(planes) if planes.shape[0] else (np.zeros((0, 4672), np.float32), np.zeros((0,), np.float32))
+        e.search_expand(lg, v)
+        r = e.search_result(0)
+        if r["finished"]:
+            return r
+    raise AssertionError("search did not finish")
+
+
+def _compare(res, want, prior_tol=1e-6):
+    assert res["moves"] == [uci(c) for c in want["moves"]]
+    assert res["idx"].tolist() == want["idx"]
+    assert res["n"].tolist() == want["n"], (res["n"].tolist(), want["n"])
+    np.testing.assert_allclose(res["prior"], want["prior"], rtol=0, atol=prior_tol)
+    np.testing.assert_allclose(res["q"], want["q"], rtol=0, atol=1e-9)
+    assert res["root_n"] == want["root_n"]
+    assert abs(res["root_q"] - want["root_q"]) < 1e-9
+
+
+def test_whole_searches_match_reference_traces():
+    """MCTS.run: 96-simulation searches on 10 positions (sharp and flat policies, with and without Dirichlet noise), a
+    300-simulation search at the reference's batch of 96, full-softmax mode, both cpuct schedules, two 1600-simulation
+    searches (BASELINE configs[4] search length), playout cap, value_from_white."""
+    n = 0
+    for case in G["runs"]:
+        if case["tt"] != "off":
+            continue
+        mcts = dict(BASE, **case["mcts_extra"])
+        e = _engine(mcts, case["seed"], case["L"])
+        net = HashNet(**case["net"])
+        want = case["results"][0]
+        e.search_begin(0, FENS[case["fen"]], want["sims"], case["dirichlet"], case["uid"])
+        res = _search(e, net)
+        _compare(res, want)
+        assert net.calls == case["evals"], case["name"]        # same number of network evaluations as the reference made
+        pi = np.zeros(4672, np.float32)
+        tot = int(res["n"].sum())
+        for i, k in zip(res["idx"], res["n"]):
+            pi[i] = np.float32(int(k) / tot)                      # _policy_from_root, mcts.py:828-837
+        nz = np.nonzero(pi)[0]
+        assert nz.tolist() == want["pi_idx"] and [float(pi[j]) for j in nz] == want["pi_val"]
+        e.close()
+        n += 1
+    assert n >= 25
+
+
+def test_expand_priors_match_reference_traces():
+    """Node._expand (mcts.py:135-225): legal-only and full softmax, entropy noise on and off, flat / sharp / very sharp
+    logits; for non-finite logits the reference dies with UnboundLocalError where its branch says 'uniform', which is what
+    the kernel computes."""
+    seed = G["expand"]["seed"]
+    for c in G["expand"]["cases"]:
+        mcts = dict(BASE, legal_softmax=c["legal_only"], enable_entropy_noise=c["noise"])
+        e = _engine(mcts, seed, 4)
+        net = HashNet(seed=c["net_seed"], sharp=c["sharp"], poison=c["poison"])
+        e.search_begin(0, FENS[c["fen"]], 1, False, c["uid"])
+        res = _search(e, net)
+        if c["raised"]:
+            np.testing.assert_allclose(res["prior"], 1.0 / len(res["prior"]), rtol=1e-6)
+        else:
+            assert res["moves"] == [uci(m) for m in c["moves"]] and res["idx"].tolist() == c["idx"]
+            np.testing.assert_allclose(res["prior"], c["prior"], rtol=0, atol=1e-6)
+        e.close()
+
+
+def test_dirichlet_matches_reference_traces():
+    """_add_dirichlet (mcts.py:955-992) for alpha below and above 1: priors after the root noise."""
+    seed = G["dirichlet"]["seed"]
+    for c in G["dirichlet"]["cases"]:
+        mcts = dict(BASE, dirichlet_alpha=c["alpha"], dirichlet_frac=c["frac"], enable_entropy_noise=False, legal_softmax=True)
+        e = _engine(mcts, seed, 4)
+        e.search_begin(0, FENS[c["fen"]], 1, True, c["uid"])
+        res = _search(e, HashNet(seed=9, sharp=8.0))
+        np.testing.assert_allclose(res["prior"], c["after"], rtol=0, atol=1e-6)       # `before` is float32-rounded in both
+        np.testing.assert_allclose(res["prior"] - np.array(c["before"]) * (1 - c["frac"]),
+                                   np.array(c["after"]) - np.array(c["before"]) * (1 - c["frac"]), rtol=0, atol=2e-7)
+        e.close()
