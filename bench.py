@@ -6,22 +6,26 @@ ResNet-24 "53M" (R24-320), 1/2/4/8 MI355X).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: for every resident game tree, select up to
-`leaves` leaves (PUCT + virtual loss), encode them into the network input, run the R24-320 forward on the
-whole batch (games x leaves positions), expand + back up, and play the moves of the searches that
-completed (800 simulations per move).  Inputs are resident in HBM; weights are random-init R24-320
-(synthetic: no checkpoint, no dataset).  One process per GPU; games shard across GPUs with no data-path
-collective (RCCL is used only to broadcast the weights from rank 0), so scaling is "weak".
+A "step" is one searched ply for every resident game: ceil(sims / leaves) passes of the hot path, each pass =
+for every resident game tree select up to `leaves` leaves (PUCT + virtual loss), encode them into the network input,
+run the R24-320 forward on the whole batch (games x leaves positions), expand + back up; searches that complete
+(800 simulations per move, +-5 % playout cap) play their move and start the next search.  `--steps 20` therefore
+searches and plays ~20 plies in each of the 256 games.  Inputs are resident in HBM; weights are random-init R24-320
+(synthetic: no checkpoint, no dataset).  One process per GPU; games shard across GPUs with no data-path collective
+(RCCL is used only to broadcast the weights from rank 0), so scaling is "weak".
 
-games/sec: games finished in the timed region / time when at least MIN_FINISHED games finish there;
-otherwise (short runs) plies/sec divided by the mean game length in plies from profiles/game_length.json
-(measured by running games to completion with this engine/config; the basis is named in the JSON line).
+games/sec: games finished in the timed region / time when at least MIN_FINISHED games finish there; otherwise the
+MEASURED plies/sec (searched and played plies counted by the engine) divided by the mean game length in plies from
+profiles/game_length.json (measured by running whole generations of games to completion with this engine/config;
+the basis is named in the JSON line).
 
 Extra objects in the JSON line:
   roofline      dominant kernel = 3x3 320->320 implicit-GEMM conv (MFMA-bound); achieved = algorithmic FLOP /
                 launch time from HIP events around every launch on the launch stream, summed over the timed region
-  cpu_baseline  the CPU oracle (oracle/mcts_ref.py + oracle/net_ref.py, torch CPU fp32) timed on this box's host
-                cores on a bounded sample, rank 0 at N=1 only
+  cpu_baseline  BASELINE configs[0] on this box's host cores: W = cores / threads worker processes, each playing one
+                self-play game at 64 sims/move with the CPU oracle (oracle/selfplay_ref.py + oracle/mcts_ref.py, reference
+                search semantics: batches of <= 96 leaves, no virtual loss) and the torch-CPU fp32 R24-320 forward, for a
+                bounded time; rank 0 at N=1 only, run BEFORE the GPU is touched so the two do not share the host
 """
 from __future__ import annotations
 
@@ -65,56 +69,94 @@ def game_length_basis():
         return DEFAULT_PLIES_PER_GAME, "default (no calibration file)"
 
 
-def cpu_baseline(seconds: float, plies_per_game: float):
-    """The CPU oracle on a bounded sample of the same workload: reference search semantics (batch of 96 leaves,
-    transposition table, no virtual loss) + fp32 torch-CPU forward of R24-320, start position, 800-sim moves
-    until `seconds` have elapsed (at least one 96-leaf batch)."""
+def host_cores() -> int:
+    """CPUs this process may use: scheduler affinity, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+CPU_CFG = {  # BASELINE configs[0]: 1 self-play game, 64 MCTS sims/move, random-init ResNet-24, device=cpu
+    "seed": 1234, "mcts": dict(SELFPLAY_CFG["mcts"]),
+    "selfplay": dict(SELFPLAY_CFG["selfplay"], num_simulations=64),
+}
+
+
+def _cpu_worker(idx: int, threads: int, seconds: float, out_q):
+    """One reference-style worker process: one game at a time (selfplay/internal.py:326), 64 sims/move."""
     import numpy as np
     import torch
-    from oracle import chess_py as ch
-    from oracle import mcts_ref as ref
-    from oracle import net_ref
-
-    cores = torch.get_num_threads()
-    sd = net_ref.random_state_dict(R24_320, seed=0)
+    torch.set_num_threads(threads)
+    from matrix0_amd.weights import random_state_dict
+    from oracle import net_ref, selfplay_ref
+    sd = random_state_dict(R24_320, seed=0, varied=True)
 
     def infer(x):
-        p, v, _ = net_ref.forward(sd, R24_320, torch.from_numpy(np.ascontiguousarray(x)))
+        with torch.no_grad():
+            p, v, _ = net_ref.forward(sd, R24_320, torch.from_numpy(np.ascontiguousarray(x)))
         return p.numpy(), v.numpy()
 
-    m = dict(SELFPLAY_CFG["mcts"])
-    cfg = ref.MCTSConfig.from_dict(dict(m, use_tt=True, virtual_loss_active=False, numerics="reference"))
-    o = ref.MCTS(cfg, infer, seed=1234, game=0)
-    b = ch.Board()
-    root = ref.Node()
-    logits, _ = o._infer_one(b)
-    o.expand(root, b, logits)
     t0 = time.perf_counter()
-    sims = 0
-    while True:
-        o.run_batched(b, root, 96)
-        sims += 96
-        if time.perf_counter() - t0 >= seconds:
-            break
+    out = selfplay_ref.play_game(CPU_CFG, infer, CPU_CFG["seed"], idx, use_tt=False, tree_reuse=False,
+                                 virtual_loss_active=False, numerics="reference", value_from_white=False, max_seconds=seconds)
     dt = time.perf_counter() - t0
-    sims_per_s = sims / dt
-    return {"value": sims_per_s / (800.0 * plies_per_game), "unit": "games/s", "cores": int(cores), "kind": "port",
-            "sims_per_s": round(sims_per_s, 2),
-            "sample": f"{sims} simulations ({sims // 96} batches of 96 leaves) of one 800-sim search from the start "
-                      f"position, oracle MCTS (TT, no virtual loss) + torch-CPU fp32 R24-320 on {cores} threads, "
-                      f"{dt:.1f} s; games/s = sims/s / (800 x {plies_per_game:.1f} plies)"}
+    out_q.put({"worker": idx, "plies": int(out["moves"]), "sims": int(sum(out["trace"]["sims"])), "evals": int(out["evals"]),
+               "secs": dt, "finished": not out["timed_out"]})
+
+
+def cpu_baseline(seconds: float, plies_per_game: float, threads: int = 4):
+    import multiprocessing as mp
+    cores = host_cores()
+    threads = max(1, min(threads, cores))
+    W = max(1, cores // threads)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    t0 = time.perf_counter()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, threads, seconds, q)) for i in range(W)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        try:
+            res.append(q.get(timeout=seconds * 6 + 300))
+        except Exception:
+            break
+    for p in procs:
+        p.join(timeout=30)
+    wall = time.perf_counter() - t0
+    if not res:
+        return {"value": None, "unit": "games/s", "cores": cores, "kind": "port", "sample": "no worker reported"}
+    span = max(r["secs"] for r in res)
+    sims = sum(r["sims"] for r in res)
+    plies = sum(r["plies"] for r in res)
+    evals = sum(r["evals"] for r in res)
+    sims_per_s = sims / span
+    return {"value": sims_per_s / (800.0 * plies_per_game), "unit": "games/s", "cores": int(cores), "workers": len(res),
+            "threads_per_worker": threads, "kind": "port", "sims_per_s": round(sims_per_s, 2), "evals_per_s": round(evals / span, 2),
+            "plies_per_s_at_64_sims": round(plies / span, 4), "games_per_s_at_64_sims": round(plies / span / plies_per_game, 6),
+            "sample": f"{len(res)} worker processes x {threads} torch threads on {cores} host cores, each one self-play game at "
+                      f"64 sims/move (BASELINE configs[0]) for {seconds:.0f} s: {plies} plies, {sims} simulations, {evals} fp32 "
+                      f"R24-320 evaluations in {span:.1f} s (wall incl. process start {wall:.1f} s); oracle = CPU restatement of the "
+                      f"reference worker (tree-only: with its transposition table on the reference raises on the 2nd move); "
+                      f"value = simulations/s / (800 x {plies_per_game:.1f} plies per game)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one searched ply per resident game")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU (BASELINE configs[1])")
     ap.add_argument("--leaves", type=int, default=16, help="leaves per tree and step (<= mcts.inference_batch_size)")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--ssl", action="store_true", help="run the 5 SSL heads in every evaluation (configs[3])")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=4, help="torch threads per CPU-baseline worker process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
@@ -128,10 +170,15 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
+    # CPU baseline first (rank 0, N=1): its worker processes are started before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds, game_length_basis()[0], args.cpu_threads)
+
     import numpy as np
     import torch
     import torch.distributed as dist
-    from oracle import net_ref                      # only random_state_dict (weight synthesis) + cpu_baseline
+    from matrix0_amd.weights import random_state_dict
     from matrix0_amd.backend import M0Backend
     from matrix0_amd import engine as eng
 
@@ -147,7 +194,7 @@ def main():
 
     # weights: rank 0 synthesises, RCCL broadcast (the optional weight broadcast of the north star)
     from matrix0_amd import dist as m0dist
-    sd = net_ref.random_state_dict(R24_320, seed=0) if rank == 0 else None
+    sd = random_state_dict(R24_320, seed=0, varied=True) if rank == 0 else None
     if distributed:
         sd = m0dist.broadcast_state_dict(sd, R24_320, src=0, device=torch.device("cuda", local_rank))
     be = M0Backend.from_state_dict(R24_320, sd, device_index=local_rank)
@@ -173,14 +220,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    substeps = -(-args.sims // args.leaves)          # passes of the hot path per searched ply
     if args.warmup > 0:
-        e.step(args.warmup)
+        e.step(args.warmup * substeps)
     be.profile_enable(True)
     be.profile_get(reset=True)
     s0 = e.stats()
     sync()
     t0 = time.perf_counter()
-    e.step(args.steps)
+    e.step(args.steps * substeps)
     sync()
     dt = time.perf_counter() - t0
     s1 = e.stats()
@@ -199,8 +247,9 @@ def main():
             games_per_s = gfin / dt_max
             basis = f"{int(gfin)} games finished in the timed region"
         else:
-            games_per_s = (sims / dt_max) / (args.sims * ppg)
-            basis = f"simulations/s / ({args.sims} sims per move x {ppg:.1f} plies per game [{basis_src}])"
+            games_per_s = (plies / dt_max) / ppg
+            basis = (f"{int(plies)} plies searched and played in the timed region / {ppg:.1f} plies per game [{basis_src}]; "
+                     f"{int(gfin)} games finished")
         achieved = (conv_flop / (conv_ms * 1e-3)) if conv_ms > 0 else 0.0
         # launch mix: conv2 of every block (and the interaction conv) also carries the fused block tail
         tail_ms, tail_n = getattr(be, "last_tail_profile", (0.0, 0))
@@ -228,8 +277,10 @@ def main():
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
-            "time_split_ms_per_step": {"net": ms_net / args.gpus / max(1, args.steps), "tree": ms_tree / args.gpus / max(1, args.steps),
-                                       "host": ms_host / args.gpus / max(1, args.steps)},
+            "passes_per_step": substeps, "ms_per_pass": dt_max * 1e3 / max(1, args.steps * substeps),
+            "time_split_ms_per_pass": {"net": ms_net / args.gpus / max(1, args.steps * substeps),
+                                       "tree": ms_tree / args.gpus / max(1, args.steps * substeps),
+                                       "host": ms_host / args.gpus / max(1, args.steps * substeps)},
             "roofline": {"bound": "mfma", "kernel": "conv_pp_kernel<*> (3x3 320->320 implicit GEMM, MFMA 32x32x16 f16)",
                          "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
@@ -237,8 +288,8 @@ def main():
                          "launch_mix": mix,
                          "whole_net_frac": (evals * flops_eval / dt_max) / (PEAK_FP16_DENSE * args.gpus)},
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, ppg)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     e.close()
     if distributed:

@@ -69,13 +69,28 @@ def param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     return out
 
 
-def random_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Fan-in scaled normal weights, unit norm gains, zero biases, logit scale 0.2 (resnet.py:476-480)."""
+def random_state_dict(cfg: dict, seed: int = 0, varied: bool = False) -> Dict[str, torch.Tensor]:
+    """Fan-in scaled normal weights, logit scale 0.2 (resnet.py:476-480).  varied=False: unit norm gains, zero biases and
+    relative-position bias (a freshly constructed module); varied=True: gains 1 +- 0.1, biases +- 0.05, relative-position
+    bias +- 0.5, running statistics perturbed -- every term of the forward carries signal, as in a trained network (the
+    synthetic weights of bench.py and of the full-size parity tests)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for name, shape in param_shapes(cfg).items():
         if name == "_policy_logit_scale_raw":
             sd[name] = torch.tensor(math.log(math.expm1(0.2 - 1e-3)))
+        elif varied and name.endswith("running_var"):
+            sd[name] = torch.rand(shape, generator=g) * 0.5 + 0.75
+        elif varied and name.endswith("running_mean"):
+            sd[name] = torch.randn(shape, generator=g) * 0.1
+        elif varied and len(shape) == 1 and name.endswith(".weight"):
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif varied and name.endswith(".bias"):
+            sd[name] = 0.05 * torch.randn(shape, generator=g)
+        elif varied and name.endswith("position_encoding"):
+            sd[name] = 0.1 * torch.randn(shape, generator=g)
+        elif varied and name.endswith("rel_bias"):
+            sd[name] = 0.5 * torch.randn(shape, generator=g)
         elif name.endswith("running_var") or (len(shape) == 1 and name.endswith(".weight")):
             sd[name] = torch.ones(shape)
         elif name.endswith("running_mean") or name.endswith(".bias") or name.endswith("rel_bias"):

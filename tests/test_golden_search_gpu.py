@@ -16,9 +16,10 @@ G = load_json("ref_mcts.json.gz")
 FENS, BASE = G["fens"], G["base_mcts"]
 
 
-def _engine(mcts, seed, L, compat=None):
+def _engine(mcts, seed, L, compat=None, sims=96):
     from matrix0_amd import engine as eng
-    cfg = eng.selfplay_cfg_from_dict({"seed": seed, "mcts": dict(mcts, inference_batch_size=L), "selfplay": {"num_simulations": 1}},
+    # num_simulations sizes the node arena (one search of new children): give it the search length
+    cfg = eng.selfplay_cfg_from_dict({"seed": seed, "mcts": dict(mcts, inference_batch_size=L), "selfplay": {"num_simulations": sims}},
                                      concurrent_games=1, virtual_loss_active=False, compat=compat)
     return eng.SelfplayEngine(None, cfg)
 
@@ -53,9 +54,9 @@ def test_whole_searches_match_reference_traces():
         if case["tt"] != "off":
             continue
         mcts = dict(BASE, **case["mcts_extra"])
-        e = _engine(mcts, case["seed"], case["L"])
-        net = HashNet(**case["net"])
         want = case["results"][0]
+        e = _engine(mcts, case["seed"], case["L"], sims=want["sims"])
+        net = HashNet(**case["net"])
         e.search_begin(0, FENS[case["fen"]], want["sims"], case["dirichlet"], case["uid"])
         res = _search(e, net)
         _compare(res, want)
