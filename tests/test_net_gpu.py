@@ -1,8 +1,14 @@
 """GPU parity: HIP network forward (through the C-ABI / infer_np seam) vs the fp32 oracle
 and vs the reference golden vectors.
 
-Tolerances (fp16 MFMA operands, fp32 accumulate, fp16 activations in HBM vs fp32 reference;
-SURVEY App. A.3): max|dlogit| <= 5e-2, |dv| <= 1e-2, KL(softmax) <= 1e-3."""
+Tolerances (fp16 MFMA operands, fp32 accumulate, fp16 activations in HBM vs the fp32 reference), set from what the
+hardware delivers (tools/net_margins.py on an MI355X, round 2: max|dlogit| 7.2e-4 on logits spanning +-0.43, |dv| 5.4e-4,
+relative L2 1.5e-3, SSL maps 4e-3 on values spanning +-2, top-1 over the legal moves identical on 256/256 positions):
+    max|dlogit| <= 5e-3    |dv| <= 2e-3    ||dp|| / ||p|| <= 5e-3    SSL <= 1e-2    KL(softmax) <= 1e-5
+    top-1 over legal moves agrees on >= 99 % of real positions
+Every comparison appends its observed maxima to gpurun_out/net_parity.jsonl so the record shows the margin."""
+import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -12,8 +18,36 @@ from tests.golden_util import load_net_golden
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 5e-2
-VALUE_TOL = 1e-2
+LOGIT_TOL = 5e-3
+VALUE_TOL = 2e-3
+REL_L2_TOL = 5e-3
+SSL_TOL = 1e-2
+KL_TOL = 1e-5
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(tag, p, v, p_ref, v_ref, ssl=None, ssl_ref=None):
+    """All network tolerances in one place; observed values go to stdout and gpurun_out/net_parity.jsonl."""
+    p_ref = np.asarray(p_ref, np.float32); v_ref = np.asarray(v_ref, np.float32)
+    obs = {"case": tag, "dlogit": float(np.abs(p - p_ref).max()), "logit_absmax": float(np.abs(p_ref).max()),
+           "dv": float(np.abs(v - v_ref).max()), "rel_l2": float(np.linalg.norm(p - p_ref) / max(1e-30, np.linalg.norm(p_ref))),
+           "kl": _kl(p_ref, p)}
+    if ssl_ref:
+        obs["ssl"] = {t: float(np.abs(ssl[t] - np.asarray(r)).max()) for t, r in ssl_ref.items()}
+    print("net parity", json.dumps(obs))
+    try:
+        os.makedirs(os.path.join(_ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(_ROOT, "gpurun_out", "net_parity.jsonl"), "a") as f:
+            f.write(json.dumps(obs) + "\n")
+    except OSError:
+        pass
+    assert obs["dlogit"] <= LOGIT_TOL, obs
+    assert obs["dv"] <= VALUE_TOL, obs
+    assert obs["rel_l2"] <= REL_L2_TOL, obs
+    assert obs["kl"] <= KL_TOL, obs
+    for t, e in obs.get("ssl", {}).items():
+        assert e <= SSL_TOL, (t, obs)
+    return obs
 
 
 def _kl(p_ref, p):
@@ -33,11 +67,7 @@ def test_hip_net_matches_reference_golden(name):
         p, v = be.infer_np(x)
         ssl = {}
     assert p.shape == p_ref.shape and v.shape == v_ref.shape
-    assert np.abs(p - p_ref).max() <= LOGIT_TOL
-    assert np.abs(v - v_ref).max() <= VALUE_TOL
-    assert _kl(p_ref, p) <= 1e-3
-    for t, ref in ssl_ref.items():
-        assert np.abs(ssl[t] - ref).max() <= 5e-2, t
+    _check(f"golden:{name}", p, v, p_ref, v_ref, ssl, ssl_ref)
     assert be.param_count() == sum(int(np.prod(t.shape)) for t in sd.values())
 
 
@@ -71,11 +101,7 @@ def test_r24_320_vs_oracle():
     x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
     p_ref, v_ref, ssl_ref = net_ref.forward(sd, cfg, x, return_ssl=True)
     p, v, ssl = be.infer_np_ssl(x.numpy())
-    assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
-    assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
-    assert _kl(p_ref.numpy(), p) <= 1e-3
-    for t in ssl_ref:
-        assert np.abs(ssl[t] - ssl_ref[t].numpy()).max() <= 1e-1, t
+    _check("r24_320:random_planes", p, v, p_ref.numpy(), v_ref.numpy(), ssl, {t: r.numpy() for t, r in ssl_ref.items()})
     # single position + repeated call determinism
     p1, v1 = be.infer_np(x[0].numpy())
     assert np.array_equal(p1[0], p[0]) and v1[0] == v[0]
@@ -100,12 +126,11 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
         p_split, v_split = be.infer_np(x.numpy())
         monkeypatch.setenv("M0_FUSE_TAIL", "1")
         p_fused, v_fused = be.infer_np(x.numpy())
-        assert np.abs(p_fused - p_split).max() <= 5e-3
-        assert np.abs(v_fused - v_split).max() <= 5e-3
+        assert np.abs(p_fused - p_split).max() <= 2e-3
+        assert np.abs(v_fused - v_split).max() <= 2e-3
         p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
-        for p, v in ((p_split, v_split), (p_fused, v_fused)):
-            assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
-            assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
+        for tag, p, v in (("split", p_split, v_split), ("fused", p_fused, v_fused)):
+            _check(f"tail_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
 
 
 def test_fused_attention_block_matches_split_kernels(monkeypatch):
@@ -135,12 +160,11 @@ def test_fused_attention_block_matches_split_kernels(monkeypatch):
         p_split, v_split = be.infer_np(x.numpy())
         monkeypatch.setenv("M0_FUSE_ATTN", "1")
         p_fused, v_fused = be.infer_np(x.numpy())
-        assert np.abs(p_fused - p_split).max() <= 5e-3, extra
-        assert np.abs(v_fused - v_split).max() <= 5e-3, extra
+        assert np.abs(p_fused - p_split).max() <= 2e-3, extra
+        assert np.abs(v_fused - v_split).max() <= 2e-3, extra
         p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
-        for p, v in ((p_split, v_split), (p_fused, v_fused)):
-            assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL, extra
-            assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL, extra
+        for tag, p, v in (("split", p_split, v_split), ("fused", p_fused, v_fused)):
+            _check(f"attn_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
         be.close()
 
 
@@ -163,11 +187,71 @@ def test_shipped_config_288x22_zero_padded_trunk():
     x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
     p_ref, v_ref, ssl_ref = net_ref.forward(sd, cfg, x, return_ssl=True)
     p, v, ssl = be.infer_np_ssl(x.numpy())
-    assert np.abs(p - p_ref.numpy()).max() <= LOGIT_TOL
-    assert np.abs(v - v_ref.numpy()).max() <= VALUE_TOL
-    assert _kl(p_ref.numpy(), p) <= 1e-3
-    for t in ssl_ref:
-        assert np.abs(ssl[t] - ssl_ref[t].numpy()).max() <= 1e-1, t
+    _check("shipped_288x22", p, v, p_ref.numpy(), v_ref.numpy(), ssl, {t: r.numpy() for t, r in ssl_ref.items()})
+
+
+def test_r24_320_top1_over_legal_moves_on_real_positions():
+    """identical top-1 prior over the legal moves on >= 99 % of positions -- 256 positions of the
+    reference's tactical set, R24-320 with the benchmark's synthetic weights, vs the fp32 oracle."""
+    import gzip
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd.weights import random_state_dict
+    from oracle import chess_py as ch
+    cfg = _r24_cfg()
+    sd = random_state_dict(cfg, seed=0, varied=True)
+    be = M0Backend.from_state_dict(cfg, sd)
+    rows = json.load(gzip.open(os.path.join(_ROOT, "tests", "golden", "tactical_legal_counts.json.gz"), "rt"))
+    boards = [ch.Board(r[0]) for r in rows[::40][:256]]
+    x = np.stack([ch.encode_board(b) for b in boards])
+    masks = np.stack([ch.get_legal_actions(b) for b in boards])
+    p, v, ssl = be.infer_np_ssl(x)
+    with torch.no_grad():
+        p_ref, v_ref, ssl_ref = net_ref.forward(sd, cfg, torch.from_numpy(x), return_ssl=True)
+    _check("r24_320:real_positions", p, v, p_ref.numpy(), v_ref.numpy(), ssl, {t: r.numpy() for t, r in ssl_ref.items()})
+    a = np.where(masks, p, -np.inf).argmax(1)
+    b = np.where(masks, p_ref.numpy(), -np.inf).argmax(1)
+    agree = float((a == b).mean())
+    print("top-1 over legal moves agreement:", agree)
+    assert agree >= 0.99
+
+
+def test_from_checkpoint_reads_the_reference_checkpoint_layout(tmp_path):
+    """M0Backend.from_checkpoint on .pt files in the reference's dict layout (create_v2_checkpoint.py:64-77): the weights are
+    taken from model_ema, else model, else model_state_dict, else the raw dict (selfplay/internal.py:172-174,
+    orchestrator.py:373-388); the duplicate alias keys a reference state_dict carries (ssl_head.* / ssl_piece_head.* =
+    ssl_heads.piece.*, resnet.py:359-444) and unknown keys are ignored; a missing tensor is an error here (the reference
+    re-initialises it silently, resnet.py:1418-1440)."""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd.weights import random_state_dict
+    cfg = dict(planes=19, channels=64, blocks=3, attention_heads=4, policy_size=4672, norm="group", activation="silu",
+               preact=True, policy_factor_rank=32, self_supervised=True, ssl_tasks=["piece", "control"])
+    good = random_state_dict(cfg, seed=21, varied=True)
+    other = random_state_dict(cfg, seed=22, varied=True)
+    with_alias = dict(good)
+    for k, t in good.items():
+        if k.startswith("ssl_heads.piece."):
+            with_alias["ssl_head." + k[len("ssl_heads.piece."):]] = t.clone()
+            with_alias["ssl_piece_head." + k[len("ssl_heads.piece."):]] = t.clone()
+    with_alias["optimizer_leftover.weight"] = torch.zeros(3)
+    x = np.zeros((2, 19, 8, 8), np.float32); x[:, 12] = 1.0; x[0, 0, 6, :] = 1.0; x[1, 5, 7, 4] = 1.0
+    want_p, want_v = M0Backend.from_state_dict(cfg, good).infer_np(x)
+    layouts = {
+        "ema_first": {"model_ema": with_alias, "model": other, "model_state_dict": other, "optimizer": {"state": {}}, "global_step": 7},
+        "model_then": {"model": with_alias, "model_state_dict": other, "version": "v2"},
+        "model_state_dict": {"model_state_dict": with_alias, "model_config": cfg},
+        "raw": with_alias,
+    }
+    for name, blob in layouts.items():
+        path = str(tmp_path / f"{name}.pt")
+        torch.save(blob, path)
+        be = M0Backend.from_checkpoint(cfg, path)
+        p, v = be.infer_np(x)
+        assert np.array_equal(p, want_p) and np.array_equal(v, want_v), name
+        be.close()
+    broken = {k: t for k, t in good.items() if k != "tower.1.conv2.weight"}
+    torch.save({"model": broken}, str(tmp_path / "broken.pt"))
+    with pytest.raises((RuntimeError, ValueError)):
+        M0Backend.from_checkpoint(cfg, str(tmp_path / "broken.pt"))
 
 
 def test_full_size_batch_invariance_and_determinism():
