@@ -122,6 +122,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
         }
     };
 
+#ifdef PP_MFMA16
+    // timing experiment (tools/ubench/conv_pp_bench.hip): the same fragment reads feeding 40 v_mfma_f32_16x16x32_f16 per
+    // half-tile instead of 20 v_mfma_f32_32x32x16_f16 -- same FLOP, same LDS bytes, same accumulator registers (results wrong)
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    float4v acc16[4][2 * NT];
+    static_for<0, 4>([&](auto mi) __attribute__((always_inline)) {
+        static_for<0, 2 * NT>([&](auto ni) __attribute__((always_inline)) {
+            acc16[decltype(mi)::value][decltype(ni)::value] = float4v{0.f, 0.f, 0.f, 0.f};
+        });
+    });
+#endif
     float16v acc[2][NT];
     static_for<0, 2>([&](auto mi) __attribute__((always_inline)) {
         static_for<0, NT>([&](auto ni) __attribute__((always_inline)) {
@@ -253,6 +264,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                 PP_BARRIER();
                 PP_FENCE();
                 PP_SETPRIO(1);
+#ifdef PP_MFMA16
+                static_for<0, 2 * NT>([&](auto n_) __attribute__((always_inline)) {
+                    constexpr int n = decltype(n_)::value;
+                    const half8 bfrag = gb[n / NT][n % NT];
+                    acc16[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga0[0], bfrag, acc16[0][n], 0, 0, 0);
+                    acc16[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga0[1], bfrag, acc16[1][n], 0, 0, 0);
+                    acc16[2][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga1[0], bfrag, acc16[2][n], 0, 0, 0);
+                    acc16[3][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga1[1], bfrag, acc16[3][n], 0, 0, 0);
+                    if constexpr (n == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+                });
+#else
                 static_for<0, 2>([&](auto u_) __attribute__((always_inline)) {
                     constexpr int u = decltype(u_)::value;
                     static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
@@ -262,6 +284,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                         if constexpr (u == 0 && ni == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
                     });
                 });
+#endif
                 PP_SETPRIO(0);
                 PP_FENCE();
                 PP_BARRIER();
@@ -349,6 +372,12 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     // still on their way into the same LDS bytes.
     __builtin_amdgcn_s_barrier();
 
+#ifdef PP_MFMA16
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2 * NT; ++ni) asm volatile("" :: "v"(acc16[mi][ni]));
+#endif
 #ifdef PP_NO_EPILOGUE
     asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[0][4]));
     asm volatile("" :: "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]), "v"(acc[1][3]), "v"(acc[1][4]));

@@ -7,7 +7,9 @@
 #include <string.h>
 #include <chrono>
 #include <deque>
+#include <list>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 #include "../../include/m0_engine.h"
@@ -86,6 +88,9 @@ struct m0_selfplay {
     int last_rows = 0;
     int rows2[2] = {0, 0};                // rows of the last select per network
     std::vector<Pos> book;                // opening positions (m0_selfplay_set_openings)
+    // LRUCache nn_cache of the reference (mcts.py:44-59, 303, 360-371): positions whose root was re-evaluated; 10 000 entries
+    std::list<uint64_t> nn_lru;
+    std::unordered_map<uint64_t, std::list<uint64_t>::iterator> nn_map;
     bool ext_pending = false;             // ext_select done, ext_expand outstanding
 };
 
@@ -109,6 +114,22 @@ void fill_tree_cfg(const m0_selfplay_cfg& c, TreeCfg& t) {
     t.dirichlet_alpha = c.dirichlet_alpha; t.dirichlet_frac = c.dirichlet_frac; t.legal_softmax = c.legal_softmax;
     t.enable_entropy_noise = c.enable_entropy_noise; t.no_instant_backtrack = c.no_instant_backtrack;
     t.virtual_loss_active = c.virtual_loss_active; t.leaves_per_step = c.inference_batch_size;
+    t.tt_merge = c.tt_merge; t.raw_legal_priors = c.raw_legal_priors; t.max_children = c.max_children;
+    t.min_child_prior = c.min_child_prior;
+}
+
+// mcts.py:359-371: a root that run() finds already in its table is evaluated again unless the position sits in nn_cache
+// (which only this branch fills).  Returns true when the evaluation has to be made; updates the LRU either way.
+bool nn_cache_miss(m0_selfplay* sp, uint64_t key) {
+    auto it = sp->nn_map.find(key);
+    if (it != sp->nn_map.end()) {
+        sp->nn_lru.splice(sp->nn_lru.end(), sp->nn_lru, it->second);
+        return false;
+    }
+    sp->nn_lru.push_back(key);
+    sp->nn_map[key] = std::prev(sp->nn_lru.end());
+    if (sp->nn_lru.size() > 10000) { sp->nn_map.erase(sp->nn_lru.front()); sp->nn_lru.pop_front(); }
+    return true;
 }
 
 void seed_game_dev(GameDev& g, uint64_t base, int uid) {
@@ -143,6 +164,7 @@ void arm_search(m0_selfplay* sp, int slot, const Pos& pos, const RepWindow& win,
     g.root_fresh = fresh ? 1 : 0;
     g.flip_root_v = (sp->cfg.value_from_white && pos.turn == BLACK) ? 1 : 0;
     g.finished = 0; g.nsamples = 0;
+    g.reinfer = (sp->cfg.root_reinfer && !fresh && nn_cache_miss(sp, tkey(pos))) ? 1 : 0;
     sp->prev_done[slot] = 0;
     push_hist(sp, slot, win);
 }
@@ -202,7 +224,7 @@ void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv
     const bool cap_draws = c.playout_random_frac > 0.0 && c.num_simulations > 0;
     int sims = playout_cap(c.num_simulations, c.playout_random_frac, cap_draws ? hgm.rng.next() : 0.0);
     hgm.cur_sims = sims;
-    if (c.fresh_tree_per_move) child_slot = -1;
+    if (c.fresh_tree_per_move || c.tt_merge) child_slot = -1;   // tt_merge: the table lives for one search (see m0_engine.h)
     const bool dir = c.dirichlet_plies < 0 || hgm.nstates < c.dirichlet_plies;
     arm_search(sp, slot, hgm.pos, hgm.win, sims, dir, child_slot < 0);
     adv_ids.push_back(slot);
@@ -285,7 +307,13 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
         if (c.ssl_targets) hgm.rec_pos.push_back(hgm.pos);
         hgm.masks.resize((T + 1) * 4672, 0);
         uint8_t* mk = hgm.masks.data() + T * 4672;
-        for (int i = 0; i < k; ++i) mk[R.child_idx[i]] = 1;
+        if (c.max_children > 0 || c.min_child_prior > 0.0) {          // pruned roots: the mask is still ALL legal moves
+            Move lm[M0_MAX_MOVES];
+            const int nl = gen_legal(hgm.pos, lm);
+            for (int i = 0; i < nl; ++i) mk[move_to_index(hgm.pos, lm[i])] = 1;
+        } else {
+            for (int i = 0; i < k; ++i) mk[R.child_idx[i]] = 1;
+        }
     }
     // entropy of pi (internal.py:430-436)
     {
@@ -493,7 +521,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     long want = cfg->arena_nodes > 0 ? cfg->arena_nodes : (long)(cfg->num_simulations * 1.3 + 64) * 96;
     if (want < 4096) want = 4096;
     sp->cap = (int)want;
-    sp->rows_max = (sp->G * sp->L + 3) & ~3;
+    sp->rows_max = (sp->G * (sp->L + 1) + 3) & ~3;      // L leaves + the re-evaluation of a reused root, per game
     const int nreg = nh_b ? 2 : 1;                    // batch regions: one per network
     memset(&sp->stats, 0, sizeof(sp->stats));
     memset(&sp->d, 0, sizeof(sp->d));
@@ -504,9 +532,23 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     t.n = dalloc<int>(sp, N); t.vl = dalloc<int>(sp, N); t.cbase = dalloc<int>(sp, N);
     t.nch = dalloc<int16_t>(sp, N); t.mv = dalloc<uint16_t>(sp, N); t.midx = dalloc<uint16_t>(sp, N);
     sp->d.games = dalloc<GameDev>(sp, sp->G);
-    sp->d.samples = dalloc<Sample>(sp, (size_t)sp->G * sp->L);
-    sp->d.paths = dalloc<int>(sp, (size_t)sp->G * sp->L * M0_MAX_DEPTH);
-    sp->d.leaf_moves = dalloc<uint16_t>(sp, (size_t)sp->G * sp->L * M0_MAX_CHILDREN);
+    const size_t LS = (size_t)sp->L + 1;
+    sp->d.samples = dalloc<Sample>(sp, (size_t)sp->G * LS);
+    sp->d.paths = dalloc<int>(sp, (size_t)sp->G * LS * M0_MAX_DEPTH);
+    sp->d.leaf_moves = dalloc<uint16_t>(sp, (size_t)sp->G * LS * M0_MAX_CHILDREN);
+    if (cfg->tt_merge) {
+        int tc = 1024;
+        while (tc < 2 * sp->cap) tc <<= 1;
+        sp->d.tt_cap = tc;
+        sp->d.epaths = dalloc<int>(sp, (size_t)sp->G * LS * M0_MAX_DEPTH);
+        sp->d.tt_keys = dalloc<uint64_t>(sp, (size_t)sp->G * tc);
+        sp->d.tt_nodes = dalloc<int>(sp, (size_t)sp->G * tc);
+        if (!sp->d.epaths || !sp->d.tt_keys || !sp->d.tt_nodes) {
+            m0_set_error("hipMalloc failed for the position tables (tt_merge): lower concurrent_games or arena_nodes");
+            m0_selfplay_destroy(sp);
+            return nullptr;
+        }
+    }
     sp->d.hist = dalloc<uint64_t>(sp, (size_t)sp->G * M0_HIST_CAP);
     sp->d.results = dalloc<RootResult>(sp, sp->G);
     sp->d.row_counter = dalloc<int>(sp, 4);
@@ -532,7 +574,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     for (auto& g : sp->hg) memset(&g, 0, sizeof(GameDev));
     sp->games.assign(sp->G, HostGame());
     sp->hres.resize(sp->G);
-    sp->hsamples.resize((size_t)sp->G * sp->L);
+    sp->hsamples.resize((size_t)sp->G * (sp->L + 1));
     sp->prev_done.assign(sp->G, 0);
     (void)hipEventCreate(&sp->ev0); (void)hipEventCreate(&sp->ev1); (void)hipEventCreate(&sp->ev2); (void)hipEventCreate(&sp->ev3);
     if (sp->net) {
@@ -608,12 +650,12 @@ int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_ro
     if (r > 0) {
         if (!planes || r > max_rows) { m0_set_error("planes buffer too small"); return M0_ERR_INVALID; }
         if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
-        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * sp->L, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * (sp->L + 1), hipMemcpyDeviceToHost);
         for (int g = 0; g < sp->G; ++g) {
             if (!sp->hg[g].active) continue;
             for (int s = 0; s < sp->hg[g].nsamples; ++s) {
-                const Sample& smp = sp->hsamples[(size_t)g * sp->L + s];
-                if ((smp.kind == 1 || smp.kind == 2) && smp.row >= 0 && smp.row < r)
+                const Sample& smp = sp->hsamples[(size_t)g * (sp->L + 1) + s];
+                if ((smp.kind == 1 || smp.kind == 2 || smp.kind == 4) && smp.row >= 0 && smp.row < r)
                     encode_planes_f32(smp.pos, planes + (size_t)smp.row * 19 * 64);
             }
         }
@@ -713,12 +755,12 @@ int m0_search_select(m0_selfplay* sp, int* rows, float* planes, int max_rows) {
     if (planes && r > 0) {
         if (r > max_rows) { m0_set_error("planes buffer too small"); return M0_ERR_INVALID; }
         if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
-        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * sp->L, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * (sp->L + 1), hipMemcpyDeviceToHost);
         for (int g = 0; g < sp->G; ++g) {
             if (!sp->hg[g].active) continue;
             for (int s = 0; s < sp->hg[g].nsamples; ++s) {
-                const Sample& smp = sp->hsamples[(size_t)g * sp->L + s];
-                if ((smp.kind == 1 || smp.kind == 2) && smp.row >= 0 && smp.row < r)
+                const Sample& smp = sp->hsamples[(size_t)g * (sp->L + 1) + s];
+                if ((smp.kind == 1 || smp.kind == 2 || smp.kind == 4) && smp.row >= 0 && smp.row < r)
                     encode_planes_f32(smp.pos, planes + (size_t)smp.row * 19 * 64);
             }
         }
@@ -779,8 +821,9 @@ int m0_search_advance(m0_selfplay* sp, int g, int slot, int sims, int dirichlet)
     hgm.win.push(hgm.pos, mv);
     make_move(hgm.pos, mv);
     hgm.history.push_back(mv);
-    arm_search(sp, g, hgm.pos, hgm.win, sims, dirichlet != 0, false);
-    std::vector<int> ids{g}, slots{slot};
+    const bool fresh = sp->cfg.fresh_tree_per_move || sp->cfg.tt_merge;
+    arm_search(sp, g, hgm.pos, hgm.win, sims, dirichlet != 0, fresh);
+    std::vector<int> ids{g}, slots{fresh ? -1 : slot};
     if (apply_advances(sp, ids, slots) != 0) { m0_set_error("advance failed"); return M0_ERR_HIP; }
     return M0_OK;
 }

@@ -27,6 +27,11 @@ struct TreeCfg {              // MCTSConfig fields the kernels read (mcts.py:61-
     int no_instant_backtrack;
     int virtual_loss_active;  // 1: apply the in-flight penalty as written (mcts.py:889-890, 922-923)
     int leaves_per_step;      // L = inference_batch_size per tree
+    // compatibility switches (include/m0_engine.h, m0_selfplay_cfg)
+    int tt_merge;             // mcts.py:919 + 1330-1346: children registered in a position table, select follows the table
+    int raw_legal_priors;     // mcts.py:227-256 for non-root expansions
+    int max_children;         // mcts.py:806-826
+    double min_child_prior;
 };
 
 // Per-game control block (host writes between steps, kernels update counters).
@@ -52,12 +57,13 @@ struct GameDev {
     uint64_t ctr_jitter, ctr_noise, ctr_dir;
     uint64_t evals;           // network evaluations consumed by this game (counted by the engine)
     int net_id;               // arena: which network evaluates this game's current search (0 / 1); self-play: 0
-    int pad_;
+    int reinfer;              // evaluate the (reused) root once more at the first select of this search (mcts.py:359-371)
 };
 
 struct Sample {
     m0::Pos pos;              // leaf position
-    int kind;                 // 0 none, 1 eval+backup, 2 root init (expand only), 3 terminal (already backed up)
+    int kind;                 // 0 none, 1 eval+backup, 2 root init (expand only), 3 terminal (already backed up),
+                              // 4 root value only (re-evaluation of a reused root)
     int leaf;
     int depth;                // path has depth+1 nodes
     int row;                  // network batch row
@@ -92,9 +98,13 @@ struct RootResult {           // written when a search finishes
 struct TreeDev {
     TreeArrays t;
     GameDev* games;           // [G]
-    Sample* samples;          // [G][L]
-    int* paths;               // [G][L][M0_MAX_DEPTH]
-    uint16_t* leaf_moves;     // [G][L][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order
+    Sample* samples;          // [G][L+1]
+    int* paths;               // [G][L+1][M0_MAX_DEPTH]
+    int* epaths;              // tt_merge: [G][L+1][M0_MAX_DEPTH] the edge children chosen at each level (virtual-loss owners)
+    uint64_t* tt_keys;        // tt_merge: [G][tt_cap] position keys, 0 = empty (open addressing, linear probing)
+    int* tt_nodes;            // tt_merge: [G][tt_cap] node registered LAST under the key
+    int tt_cap;               // entries per game, a power of two
+    uint16_t* leaf_moves;     // [G][L+1][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order
     uint64_t* hist;           // [G][M0_HIST_CAP]
     RootResult* results;      // [G]
     int* row_counter;         // [2]: rows reserved for network 0 / network 1 (arena); row index = net_row_base*net + count

@@ -202,11 +202,80 @@ __device__ void encode_nhwc(const Pos& p, _Float16* dst /*[64][32]*/, int lane) 
     o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
 }
 
+// ---- position table of the tt_merge mode (MCTS._tt_get / _tt_put / _register_children_in_tt, mcts.py:1231-1346):
+// open addressing with linear probing over a per-game region; key 0 = empty; an entry holds the node registered LAST
+// under its key (the reference's dict assignment overwrites).  Cleared when a search starts from a fresh root.
+__device__ __forceinline__ uint64_t tt_key_of(const Pos& p) { const uint64_t k = tkey(p); return k ? k : 1ull; }
+__device__ __forceinline__ int tt_home(uint64_t key, int cap) { return (int)((key ^ (key >> 29)) & (uint64_t)(cap - 1)); }
+// whole-wave lookup of a wave-uniform key: 64 slots per probe round; -1 = not registered
+__device__ int tt_lookup(const uint64_t* keys, const int* nodes, int cap, uint64_t key, int lane) {
+    const int mask = cap - 1, home = tt_home(key, cap);
+    for (int it = 0; it < cap; it += 64) {
+        const uint64_t k = keys[(home + it + lane) & mask];
+        const unsigned long long hit = __ballot(k == key), emp = __ballot(k == 0ull);
+        const int fh = hit ? __builtin_ctzll(hit) : 64, fe = emp ? __builtin_ctzll(emp) : 64;
+        if (fh < fe) return nodes[(home + it + fh) & mask];
+        if (fe < 64) return -1;
+    }
+    return -1;
+}
+// per-lane insert-or-overwrite (the active lanes of one call hold distinct keys)
+__device__ void tt_insert(uint64_t* keys, int* nodes, int cap, uint64_t key, int node) {
+    const int mask = cap - 1;
+    int s = tt_home(key, cap);
+    for (int it = 0; it < cap; ++it) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(keys + s), 0ull, (unsigned long long)key);
+        if (prev == 0ull || prev == (unsigned long long)key) { nodes[s] = node; return; }
+        s = (s + 1) & mask;
+    }
+}
+
+// numpy float32 add.reduce over a[0..n): pairwise with an 8-way unrolled base case (blocks of <= 128), n <= 256
+__device__ float np_sum_f32_dev(const float* a, int n) {
+    auto block = [&](const float* b, int m) -> float {
+        if (m < 8) { float r = 0.f; for (int i = 0; i < m; ++i) r += b[i]; return r; }
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = b[j];
+        int i;
+        for (i = 8; i < m - (m % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += b[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < m; ++i) res += b[i];
+        return res;
+    };
+    if (n <= 128) return block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return block(a, n2) + block(a + n2, n - n2);
+}
+
 // MCTS._backpropagate (mcts.py:946-953): the leaf gets +v, its parent -v, ...  The nodes of a path are distinct, so
 // every level is independent: lane d updates level d (all levels' loads in flight at once instead of a chain of
 // dependent read-modify-writes by one lane); the arithmetic per node is that of the sequential loop (negation is exact).
-__device__ void backprop(const Arena& A, const int* path, int depth, double value, int lane) {   // whole-wave caller
+__device__ void backprop(const Arena& A, const int* path, int depth, double value, int lane, bool may_repeat = false) {   // whole-wave caller
     const double v = fmax(-1.0, fmin(1.0, value));
+    if (may_repeat) {
+        // tt_merge: a path can pass through the same node twice (a position repeated along the line); the reference's
+        // sequential loop then updates it twice, in path order from the leaf up -- do exactly that when it happens
+        bool dup = false;
+        for (int d = lane; d <= depth; d += 64) {
+            const int nd = path[d];
+            for (int e = 0; e < d; ++e) dup = dup || path[e] == nd;
+        }
+        if (__any(dup)) {
+            if (lane == 0) {
+                double vv = v;
+                for (int d = depth; d >= 0; --d) {
+                    const int nd = path[d];
+                    const int nn = A.n[nd] + 1;
+                    const double ww = A.w[nd] + vv;
+                    A.n[nd] = nn; A.w[nd] = ww; A.q[nd] = ww / (double)nn;
+                    vv = -vv;
+                }
+            }
+            return;
+        }
+    }
     for (int d = lane; d <= depth; d += 64) {
         const int nd = path[d];
         const int nn = A.n[nd] + 1;
@@ -244,11 +313,26 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     const int g = blockIdx.x, lane = threadIdx.x;
     GameDev* gd = &d.games[g];
     if (!gd->active) { if (lane == 0) gd->nsamples = 0; return; }
-    uint16_t* LM = d.leaf_moves + (size_t)g * d.L * M0_MAX_CHILDREN;
+    uint16_t* LM = d.leaf_moves + (size_t)g * (d.L + 1) * M0_MAX_CHILDREN;
     const Arena A = arena_of(d.t, g, gd->arena);
     const int root = gd->root;
-    Sample* S = d.samples + (size_t)g * d.L;
-    int* P = d.paths + (size_t)g * d.L * M0_MAX_DEPTH;
+    Sample* S = d.samples + (size_t)g * (d.L + 1);
+    int* P = d.paths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH;
+    int* EP = c.tt_merge ? d.epaths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH : nullptr;
+    const uint64_t* TK = c.tt_merge ? d.tt_keys + (size_t)g * d.tt_cap : nullptr;
+    const int* TN = c.tt_merge ? d.tt_nodes + (size_t)g * d.tt_cap : nullptr;
+    // mcts.py:359-371: a root taken over from the previous search is evaluated once more (value only)
+    auto emit_reinfer = [&](int at) {
+        int row = 0;
+        if (lane == 0) row = atomicAdd(d.row_counter + gd->net_id, 1) + gd->net_id * d.net_row_base;
+        row = __shfl(row, 0);
+        if (lane == 0) {
+            Sample s; s.pos = gd->root_pos; s.kind = 4; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = 0;
+            S[at] = s; gd->reinfer = 0;
+        }
+        encode_nhwc(gd->root_pos, d.x0 + (size_t)row * 64 * 32, lane);
+    };
+    const bool reinfer = gd->reinfer != 0;
 
     if (A.nch[root] < 0) {                       // root not expanded: one network evaluation, no simulation
         if (lane == 0 && !gd->root_fresh) {
@@ -265,9 +349,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         for (int i = lane; i < nl; i += 64) LM[i] = smoves[i];
         if (lane == 0) {
             Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = nl;
-            S[0] = s; P[0] = root; gd->nsamples = 1;
+            S[0] = s; P[0] = root; gd->nsamples = reinfer ? 2 : 1;
         }
         encode_nhwc(rp, d.x0 + (size_t)row * 64 * 32, lane);
+        if (reinfer) emit_reinfer(1);
         return;
     }
     if (gd->need_dirichlet) {
@@ -286,9 +371,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     for (int s = 0; s < nleaf; ++s) {
         Pos pos = gd->root_pos;
         int* path = P + (size_t)s * M0_MAX_DEPTH;
+        int* epath = c.tt_merge ? EP + (size_t)s * M0_MAX_DEPTH : nullptr;
         int node = root, depth = 0;
         int prev_from = -1, prev_to = -1;
-        if (lane == 0) path[0] = root;
+        if (lane == 0) { path[0] = root; if (epath) epath[0] = root; }
         // One round of dependent loads per level: the children scan also fetches every candidate's own node fields
         // (children ARE nodes), and the winner's are broadcast -- the next level starts without loading its node.
         int nc = A.nch[node], cb = A.cbase[node], nn = A.n[node];
@@ -341,6 +427,16 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             if (lane == 0 && c.virtual_loss_active) A.vl[child] = vlw + 1;
             prev_from = mv_from(m); prev_to = mv_to(m);
             node = child; ++depth;
+            if (c.tt_merge) {
+                // mcts.py:919: node = self._tt_get(board._transposition_key()) or best_child -- the walk continues from
+                // the node registered LAST for this position; the edge child keeps the statistics its parent scores
+                const int tn = tt_lookup(TK, TN, d.tt_cap, tt_key_of(pos), lane);
+                if (tn >= 0 && tn != child) {
+                    node = tn;
+                    nc = A.nch[node]; cb = A.cbase[node]; nn = A.n[node]; nq = A.q[node];
+                }
+                if (lane == 0) epath[depth] = child;
+            }
             if (lane == 0) path[depth] = node;
         }
         __syncthreads();
@@ -380,9 +476,10 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             S[s] = smp;
         }
         __syncthreads();                                 // path[] (lane 0) before the wave reads it
-        if (term) { backprop(A, path, depth, tv, lane); __syncthreads(); }   // mcts.py:747-751: terminal leaves back up immediately
+        if (term) { backprop(A, path, depth, tv, lane, c.tt_merge != 0); __syncthreads(); }   // mcts.py:747-751: terminal leaves back up immediately
     }
-    if (lane == 0) { gd->ctr_jitter = ctrj; gd->nsamples = nleaf; }
+    if (reinfer) emit_reinfer(nleaf);
+    if (lane == 0) { gd->ctr_jitter = ctrj; gd->nsamples = nleaf + (reinfer ? 1 : 0); }
 }
 
 __device__ __forceinline__ float wave_max_f(float v) {
@@ -399,8 +496,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // Node._expand (mcts.py:135-225) for one leaf; returns false if the arena is exhausted
+struct ExpandScratch {          // workgroup-shared staging of one expansion (raw priors / pruning only)
+    float pr[M0_MAX_CHILDREN];
+    uint16_t mv[M0_MAX_CHILDREN];
+    uint16_t idx[M0_MAX_CHILDREN];
+    uint8_t keep[M0_MAX_CHILDREN];
+    float total;
+};
+
 __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg& c, int leaf, const Pos& pos,
-                            const float* lg, const uint16_t* smoves, int n, int lane) {
+                            const float* lg, const uint16_t* smoves, int n, int lane, bool is_root, ExpandScratch* X,
+                            uint64_t* TK, int* TN, int tt_cap) {
     // legal moves of the leaf come from select (same position, same order): no second move generation
     if (n <= 0) return true;
     // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
@@ -429,7 +535,22 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
         pr[k] = 0.f; idx[k] = 0; mvv[k] = 0;
         if (i < n) { mvv[k] = smoves[i]; idx[k] = move_to_index(pos, mvv[k]); }
     }
-    if (bad) {
+    const bool raw = c.raw_legal_priors && c.legal_softmax && !is_root;
+    if (raw) {
+        // Node._expand_with_legal_priors (mcts.py:227-256), the reference's in-process-model branch (mcts.py:697-703):
+        // priors = legal logits / their float32 sum (numpy pairwise order), uniform when the sum is <= 0 or not finite;
+        // no softmax, no entropy noise, and only the LEGAL logits are looked at
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; if (i < n) X->pr[i] = lg[idx[k]]; }
+        __syncthreads();
+        if (lane == 0) X->total = np_sum_f32_dev(X->pr, n);
+        __syncthreads();
+        const float total = X->total;
+        const bool ok = isfinite(total) && total > 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; pr[k] = i < n ? (ok ? X->pr[i] / total : 1.0f / (float)n) : 0.f; }
+        __syncthreads();
+    } else if (bad) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pr[k] = 1.0f / (float)n;
     } else {
@@ -517,32 +638,72 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
             for (int k = 0; k < 4; ++k) pr[k] = 1.0f / (float)n;
         }
     }
+    // MCTS._prune_children (mcts.py:806-826): drop children below min_child_prior, then keep the max_children largest
+    // priors (Python's stable sort: ties stay in move order; the kept children are then IN sorted order); priors are
+    // not renormalised.  pos[k] = slot of this lane's k-th child in the node's child block, -1 = dropped.
+    int slot[4] = {lane, lane + 64, lane + 128, lane + 192};
+    int nkeep = n;
+    if (c.max_children > 0 || c.min_child_prior > 0.0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            if (i < n) { X->pr[i] = pr[k]; X->keep[i] = (c.min_child_prior > 0.0 && !((double)pr[k] >= c.min_child_prior)) ? 0 : 1; }
+        }
+        __syncthreads();
+        int kept = 0;
+        for (int j = 0; j < n; ++j) kept += X->keep[j];
+        const bool topk = c.max_children > 0 && kept > c.max_children;
+        nkeep = topk ? c.max_children : kept;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            slot[k] = -1;
+            if (i < n && X->keep[i]) {
+                int r = 0;
+                if (topk) { for (int j = 0; j < n; ++j) r += (X->keep[j] && (X->pr[j] > pr[k] || (X->pr[j] == pr[k] && j < i))) ? 1 : 0; }
+                else { for (int j = 0; j < i; ++j) r += X->keep[j]; }
+                if (r < nkeep) slot[k] = r;
+            }
+        }
+        __syncthreads();
+    }
     const int cb = gd->next;
-    if (cb + n > cap) { if (lane == 0) gd->overflow = 1; return false; }
+    if (cb + nkeep > cap) { if (lane == 0) gd->overflow = 1; return false; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = lane + 64 * k;
-        if (i < n) {
-            const int ci = cb + i;
+        if (i < n && slot[k] >= 0) {
+            const int ci = cb + slot[k];
             A.prior[ci] = (double)pr[k]; A.w[ci] = 0.0; A.q[ci] = 0.0; A.n[ci] = 0; A.vl[ci] = 0;
             A.cbase[ci] = -1; A.nch[ci] = -1; A.mv[ci] = mvv[k]; A.midx[ci] = (uint16_t)idx[k];
+            // _register_children_in_tt (mcts.py:1330-1346): every child of an expanded NON-root node goes into the table
+            // under the key of the position it leads to (run() registers only the fresh root itself, mcts.py:344-358)
+            if (TK && !is_root) {
+                Pos q = pos;
+                make_move(q, mvv[k]);
+                tt_insert(TK, TN, tt_cap, tt_key_of(q), ci);
+            }
         }
     }
-    if (lane == 0) { A.cbase[leaf] = cb; A.nch[leaf] = (int16_t)n; gd->next = cb + n; }
+    if (TK && is_root && lane == 0) tt_insert(TK, TN, tt_cap, tt_key_of(pos), leaf);
+    if (lane == 0) { A.cbase[leaf] = cb; A.nch[leaf] = (int16_t)nkeep; gd->next = cb + nkeep; }
     __syncthreads();
     return true;
 }
 
 __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
+    __shared__ ExpandScratch X;
     const int g = blockIdx.x, lane = threadIdx.x;
     GameDev* gd = &d.games[g];
     if (!gd->active) return;
-    const uint16_t* LM = d.leaf_moves + (size_t)g * d.L * M0_MAX_CHILDREN;
+    uint64_t* TK = c.tt_merge ? d.tt_keys + (size_t)g * d.tt_cap : nullptr;
+    int* TN = c.tt_merge ? d.tt_nodes + (size_t)g * d.tt_cap : nullptr;
+    const uint16_t* LM = d.leaf_moves + (size_t)g * (d.L + 1) * M0_MAX_CHILDREN;
     const int ns = gd->nsamples;
     if (ns <= 0) return;
     const Arena A = arena_of(d.t, g, gd->arena);
-    const Sample* S = d.samples + (size_t)g * d.L;
-    const int* P = d.paths + (size_t)g * d.L * M0_MAX_DEPTH;
+    const Sample* S = d.samples + (size_t)g * (d.L + 1);
+    const int* P = d.paths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH;
     int sims = 0;
     uint64_t evals = 0;
     for (int s = 0; s < ns; ++s) {
@@ -554,11 +715,12 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
             const float v = d.values[row];
             if (A.nch[leaf] < 0) {
                 const Pos pos = S[s].pos;
-                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane);
+                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane,
+                            kind == 2, &X, TK, TN, d.tt_cap);
             }
             ++evals;
             if (kind == 1) {
-                backprop(A, path, depth, (double)v, lane);
+                backprop(A, path, depth, (double)v, lane, c.tt_merge != 0);
                 ++sims;
             } else {
                 double rv = fmax(-1.0, fmin(1.0, (double)v));
@@ -571,6 +733,11 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
             __syncthreads();
         } else if (kind == 3) {
             ++sims;
+        } else if (kind == 4) {                   // value of a reused root (mcts.py:359-371); v is read only if root.n == 0
+            double rv = fmax(-1.0, fmin(1.0, (double)d.values[S[s].row]));
+            if (gd->flip_root_v) rv = -rv;
+            if (lane == 0) gd->root_v = rv;
+            ++evals;
         }
     }
     // release virtual losses of the whole batch (the reference's inflight dict dies with the batch)
@@ -579,7 +746,8 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
         for (int s = lane; s < ns; s += 64) {
             const int kind = S[s].kind;
             if (kind == 1 || kind == 3) {
-                const int* path = P + (size_t)s * M0_MAX_DEPTH;
+                // the in-flight counts sit on the EDGE children (tt_merge: the walk itself may have continued elsewhere)
+                const int* path = (c.tt_merge ? d.epaths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH : P) + (size_t)s * M0_MAX_DEPTH;
                 for (int dd = 1; dd <= S[s].depth; ++dd) atomicSub(&A.vl[path[dd]], 1);
             }
         }
@@ -617,6 +785,10 @@ __global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_
     GameDev* gd = &d.games[g];
     if (slot < 0) {
         const Arena D = arena_of(d.t, g, 0);
+        if (d.tt_keys) {                             // a fresh root starts with an empty position table
+            uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + (size_t)g * d.tt_cap);
+            for (int i = lane; i < d.tt_cap / 2; i += 64) tk[i] = make_uint4(0, 0, 0, 0);
+        }
         if (lane == 0) {
             D.prior[0] = 0.0; D.w[0] = 0.0; D.q[0] = 0.0; D.n[0] = 0; D.vl[0] = 0; D.cbase[0] = -1; D.nch[0] = -1;
             D.mv[0] = 0; D.midx[0] = 0;

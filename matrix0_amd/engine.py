@@ -106,10 +106,11 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     sp = dict(cfg.get("selfplay", {}) or {})
     draw = dict(cfg.get("draw", {}) or {})
     draw.update(sp.get("draw", {}) or {})
-    if int(m.get("max_children", 0) or 0) > 0 or float(m.get("min_child_prior", 0.0) or 0.0) > 0.0:
-        raise ValueError("mcts.max_children / mcts.min_child_prior (MCTS._prune_children, mcts.py:806-826) are not implemented "
-                         "in the MI355X engine; config.yaml ships them disabled (0 / 0.0)")
     c = SelfplayCfg()
+    c.max_children = int(m.get("max_children", 0) or 0)                 # MCTS._prune_children (mcts.py:806-826)
+    c.min_child_prior = float(m.get("min_child_prior", 0.0) or 0.0)
+    if c.max_children < 0 or c.max_children > 256 or c.min_child_prior < 0.0:
+        raise ValueError("mcts.max_children must be in [0, 256] and mcts.min_child_prior >= 0")
     c.num_simulations = int(sp.get("num_simulations", m.get("num_simulations", 800)))
     c.cpuct = float(sp.get("cpuct", m.get("cpuct", 2.5)))
     cs, ce, cp = m.get("cpuct_start"), m.get("cpuct_end"), int(m.get("cpuct_plies", 0) or 0)
@@ -250,7 +251,7 @@ class SelfplayEngine:
     def ext_select(self) -> np.ndarray:
         """First half of a self-play step for an external evaluator: the leaf planes f32 [rows,19,8,8]."""
         rows = c_int(0)
-        cap = self.cfg.concurrent_games * self.cfg.inference_batch_size
+        cap = self.cfg.concurrent_games * (self.cfg.inference_batch_size + 1)
         planes = np.zeros((cap, 19, 8, 8), dtype=np.float32)
         _lib.check(self._L.m0_selfplay_ext_select(self._h, C.byref(rows), planes.ctypes.data_as(C.c_void_p), cap), "m0_selfplay_ext_select")
         return planes[: rows.value]
@@ -267,7 +268,7 @@ class SelfplayEngine:
 
     def search_select(self) -> np.ndarray:
         rows = c_int(0)
-        cap = self.cfg.concurrent_games * self.cfg.inference_batch_size
+        cap = self.cfg.concurrent_games * (self.cfg.inference_batch_size + 1)
         planes = np.zeros((cap, 19, 8, 8), dtype=np.float32)
         _lib.check(self._L.m0_search_select(self._h, C.byref(rows), planes.ctypes.data_as(C.c_void_p), cap), "m0_search_select")
         return planes[: rows.value]

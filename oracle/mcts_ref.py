@@ -123,6 +123,12 @@ class MCTSConfig:
     inference_batch_size: int = 96
     playout_random_frac: float = 0.0
     enable_entropy_noise: bool = True
+    max_children: int = 0
+    min_child_prior: float = 0.0
+    # which of the reference's two expansion branches non-root leaves take: False = the inference_backend branch
+    # (Node._expand, legal softmax; mcts.py:654-664), True = the in-process-model branch when legal_softmax is set
+    # (Node._expand_with_legal_priors: legal logits / their sum, mcts.py:697-703)
+    raw_legal_priors: bool = False
     # build switches (see module docstring)
     use_tt: bool = True
     virtual_loss_active: bool = False
@@ -227,14 +233,35 @@ class MCTS:
             return float(self.cfg.draw_penalty)
         return 0.0
 
-    def expand(self, node: Node, board: ch.Board, logits: np.ndarray) -> None:
+    def prune_children(self, node: Node) -> None:
+        """MCTS._prune_children, mcts.py:806-826 (stable sort: ties keep move order; no renormalisation)."""
+        if not node.children:
+            return
+        items = list(node.children.items())
+        if self.cfg.min_child_prior > 0.0:
+            items = [(m, c) for (m, c) in items if float(c.prior) >= float(self.cfg.min_child_prior)]
+        if self.cfg.max_children and self.cfg.max_children > 0 and len(items) > self.cfg.max_children:
+            items.sort(key=lambda mc: float(mc[1].prior), reverse=True)
+            items = items[: int(self.cfg.max_children)]
+        node.children = {m: c for (m, c) in items}
+
+    def expand(self, node: Node, board: ch.Board, logits: np.ndarray, is_root: bool = False) -> None:
         if node.expanded:
             return
         moves, idxs = ch.legal_moves_with_indices(board)
         if not moves:
             return
-        lp = legal_priors(logits, idxs, self.cfg.legal_softmax, bool(self.cfg.enable_entropy_noise), self.noise,
-                          self.cfg.numerics)
+        if self.cfg.raw_legal_priors and self.cfg.legal_softmax and not is_root:
+            # Node._expand_with_legal_priors, mcts.py:227-256
+            pri = np.asarray(logits, dtype=np.float32)[idxs].astype(np.float32, copy=False)
+            total = float(pri.sum())
+            if not np.isfinite(total) or total <= 0:
+                lp = np.full(len(moves), 1.0 / len(moves), dtype=np.float32)
+            else:
+                lp = pri / total
+        else:
+            lp = legal_priors(logits, idxs, self.cfg.legal_softmax, bool(self.cfg.enable_entropy_noise), self.noise,
+                              self.cfg.numerics)
         for m, idx, p in zip(moves, idxs, lp):
             c = Node(prior=float(p), move=m, parent=node)
             c.move_idx = int(idx)
@@ -242,6 +269,7 @@ class MCTS:
                 c.q = -node.parent.q
             node.children[m] = c
         node.expanded = True
+        self.prune_children(node)
 
     def register_children(self, node: Node, board: ch.Board) -> None:
         if not self.cfg.use_tt:
@@ -350,7 +378,7 @@ class MCTS:
         if root is None:
             root = Node()
             logits, v = self._infer_one(board)
-            self.expand(root, board, logits)
+            self.expand(root, board, logits, is_root=True)
             if cfg.use_tt:
                 self.tt[key] = root
         else:
@@ -373,7 +401,7 @@ class MCTS:
             sims = sims_override            # playout-cap draw injected by the caller
         if not root.expanded:
             logits, v = self._infer_one(board)
-            self.expand(root, board, logits)
+            self.expand(root, board, logits, is_root=True)
             self.register_children(root, board)
             root.q = float(np.clip(v, -1.0, 1.0))
             if cfg.dirichlet_plies is None or ply is None or ply < int(cfg.dirichlet_plies):

@@ -107,7 +107,8 @@ def _snap(root):
 
 def _oracle_run(case, numerics="reference"):
     cfg = ref.MCTSConfig.from_dict(dict(BASE, **case["mcts_extra"], inference_batch_size=case["L"], use_tt=(case["tt"] == "on"),
-                                        virtual_loss_active=False, numerics=numerics))
+                                        virtual_loss_active=False, numerics=numerics,
+                                        raw_legal_priors=bool(case.get("model_path", False))))
     net = HashNet(**case["net"])
     o = ref.MCTS(cfg, net.infer_np, seed=case["seed"], game=case["uid"])
     game = ref.Stream(ref.derive_seed(case["seed"], case["uid"], ref.PURPOSE_GAME))

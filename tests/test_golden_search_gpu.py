@@ -1,7 +1,8 @@
 """The HIP search kernels compared DIRECTLY with traces of the real reference code (tests/golden/ref_mcts.json.gz, produced by
 running /root/reference/azchess/mcts.py: see tools/gen_golden_mcts.py) -- no oracle in between.  Same counter streams, same
 bit-reproducible evaluator (tests/hash_net.py) fed through the split-step C-ABI.  The reference has no virtual loss and, in
-these cases, its transposition table patched out (tree-only), so the engine runs with virtual_loss_active=0.
+its transposition table is either patched out (tree-only: the engine's default structure) or left on (the engine's
+compat.tt_merge); the engine runs with virtual_loss_active=0 throughout.
 
 Integer results (move order, policy indices, visit counts, simulations) must be identical; float32 priors within 1e-6
 (the tolerance of the reference's own tests/test_mcts_logits.py); float64 q / root value within 1e-9."""
@@ -45,17 +46,22 @@ def _compare(res, want, prior_tol=1e-6):
     assert abs(res["root_q"] - want["root_q"]) < 1e-9
 
 
-def test_whole_searches_match_reference_traces():
+@pytest.mark.parametrize("tt", ["off", "on"])
+def test_whole_searches_match_reference_traces(tt):
     """MCTS.run: 96-simulation searches on 10 positions (sharp and flat policies, with and without Dirichlet noise), a
     300-simulation search at the reference's batch of 96, full-softmax mode, both cpuct schedules, two 1600-simulation
-    searches (BASELINE configs[4] search length), playout cap, value_from_white."""
+    searches (BASELINE configs[4] search length), playout cap, value_from_white, MCTS._prune_children (top-K, minimum prior,
+    both), and the in-process-model branch whose non-root priors are raw legal logits over their sum
+    (Node._expand_with_legal_priors).  tt="on": the reference's transposition table untouched (search graph is a DAG),
+    against the engine's position table (compat.tt_merge)."""
     n = 0
     for case in G["runs"]:
-        if case["tt"] != "off":
+        if case["tt"] != tt or case["repeats"] != 1:
             continue
         mcts = dict(BASE, **case["mcts_extra"])
         want = case["results"][0]
-        e = _engine(mcts, case["seed"], case["L"], sims=want["sims"])
+        e = _engine(mcts, case["seed"], case["L"], sims=want["sims"],
+                    compat={"tt_merge": tt == "on", "raw_legal_priors": bool(case.get("model_path", False))})
         net = HashNet(**case["net"])
         e.search_begin(0, FENS[case["fen"]], want["sims"], case["dirichlet"], case["uid"])
         res = _search(e, net)
@@ -69,7 +75,37 @@ def test_whole_searches_match_reference_traces():
         assert nz.tolist() == want["pi_idx"] and [float(pi[j]) for j in nz] == want["pi_val"]
         e.close()
         n += 1
-    assert n >= 25
+    assert n >= 30
+
+
+def test_reused_root_is_evaluated_again_unless_cached():
+    """compat.root_reinfer (mcts.py:359-371, LRUCache mcts.py:44-59): a root taken over from the previous search costs one
+    more evaluation, except when the position was a reused root before (nn_cache hit).  Same visit counts either way; the
+    evaluation count follows the oracle, which is pinned to the reference on this (same_board_x3 in ref_mcts.json.gz)."""
+    from oracle import chess_py as ch
+    from oracle import mcts_ref as ref
+    mcts = dict(BASE)
+    for reinfer in (False, True):
+        e = _engine(mcts, 77, 8, sims=48, compat={"root_reinfer": reinfer})
+        net = HashNet(seed=12, sharp=8.0)
+        o_net = HashNet(seed=12, sharp=8.0)
+        o = ref.MCTS(ref.MCTSConfig.from_dict(dict(mcts, inference_batch_size=8, use_tt=False, virtual_loss_active=False,
+                                                   numerics="engine")), o_net.infer_np, seed=77, game=5)
+        b = ch.Board(FENS[1])
+        e.search_begin(0, FENS[1], 48, True, 5)
+        for ply in range(4):
+            res = _search(e, net)
+            vc, _, _ = o.run(b, num_simulations=48, ply=ply)
+            assert res["n"].tolist() == list(vc.values())
+            slot = int(np.argmax(res["n"]))
+            mv = ch.Move.from_uci(res["moves"][slot])
+            o.note_move_played(mv)
+            b.push(mv)
+            if ply < 3:
+                e.search_advance(0, slot, 48, True)
+        # the oracle always re-evaluates a reused root (reference behaviour); the engine only with the switch
+        assert net.calls == (o_net.calls if reinfer else o_net.calls - 3), (reinfer, net.calls, o_net.calls)
+        e.close()
 
 
 def test_expand_priors_match_reference_traces():

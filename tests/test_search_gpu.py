@@ -190,7 +190,11 @@ def test_c_base_cpuct_schedule_and_long_search():
         assert sum(results[g]["n"]) == sims
 
 
-def test_unsupported_pruning_fails_loudly():
+def test_pruning_config_is_validated():
     from matrix0_amd import engine as eng
-    with pytest.raises(ValueError, match="_prune_children"):
-        eng.selfplay_cfg_from_dict({"mcts": {"max_children": 8}}, concurrent_games=1)
+    cfg = eng.selfplay_cfg_from_dict({"mcts": {"max_children": 8, "min_child_prior": 0.01}}, concurrent_games=1)
+    assert cfg.max_children == 8 and abs(cfg.min_child_prior - 0.01) < 1e-12
+    with pytest.raises(ValueError):
+        eng.selfplay_cfg_from_dict({"mcts": {"max_children": 1000}}, concurrent_games=1)
+    with pytest.raises(ValueError, match="compat"):
+        eng.selfplay_cfg_from_dict({}, concurrent_games=1, compat={"no_such_switch": True})

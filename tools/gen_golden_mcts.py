@@ -163,7 +163,26 @@ class Nop:
         pass
 
 
-def new_mcts(mcfg, net):
+class TorchModel:
+    """The evaluator as an in-process `model` (mcts.py:672-687, 1053-1078): called with a torch tensor, returns tensors."""
+
+    class _Cfg:
+        policy_size = 4672
+
+    cfg = _Cfg()
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, x):
+        import torch
+        p, v = self.net.infer_np(x.detach().cpu().numpy())
+        return torch.from_numpy(p), torch.from_numpy(v)
+
+
+def new_mcts(mcfg, net, model_path=False):
+    if model_path:          # the branch that expands non-root leaves with Node._expand_with_legal_priors (mcts.py:697-703)
+        return rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), TorchModel(net), device="cpu", inference_backend=None)
     return rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=net)
 
 
@@ -284,10 +303,10 @@ def gen_mcts():
     # -- whole MCTS.run (mcts.py:318-512)
     runs = []
 
-    def run_case(name, fen_i, sims, L, tt, seed, uid, net_kw, extra=None, dirichlet=True, repeats=1):
+    def run_case(name, fen_i, sims, L, tt, seed, uid, net_kw, extra=None, dirichlet=True, repeats=1, model_path=False):
         mcfg = dict(BASE_MCTS, inference_batch_size=L, **(extra or {}))
         net = HashNet(**net_kw)
-        mc = new_mcts(mcfg, net)
+        mc = new_mcts(mcfg, net, model_path)
         b = chess.Board(FENS[fen_i])
         st = refshim.Streams(seed, uid)
         res = []
@@ -296,7 +315,7 @@ def gen_mcts():
                 vc, pi, rq = mc.run(b, num_simulations=sims, ply=(0 if dirichlet else 1000))
                 res.append(root_dump(mc, vc, pi, rq))
         runs.append({"name": name, "fen": fen_i, "sims": sims, "L": L, "tt": tt, "seed": seed, "uid": uid, "net": net_kw,
-                     "mcts_extra": extra or {}, "dirichlet": dirichlet, "repeats": repeats, "results": res,
+                     "mcts_extra": extra or {}, "dirichlet": dirichlet, "repeats": repeats, "results": res, "model_path": model_path,
                      "evals": net.calls, "tt_entries": len(mc.tt),
                      "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
         print("run", name, "fen", fen_i, "sims", sims, "tt", tt, "evals", net.calls, "root_n", res[-1]["root_n"], flush=True)
@@ -324,6 +343,17 @@ def gen_mcts():
         uid += 1
         run_case("value_from_white", 3, 48, 8, tt, 1234, uid, {"seed": 7, "sharp": 8.0, "stm_oriented": False},
                  extra={"value_from_white": True})
+        # MCTS._prune_children (mcts.py:806-826)
+        uid += 1
+        run_case("prune_topk", 1, 128, 8, tt, 1234, uid, {"seed": 31, "sharp": 8.0}, extra={"max_children": 6})
+        uid += 1
+        run_case("prune_minprior", 3, 128, 8, tt, 1234, uid, {"seed": 32, "sharp": 10.0}, extra={"min_child_prior": 0.03})
+        uid += 1
+        run_case("prune_both", 0, 200, 16, tt, 1234, uid, {"seed": 33, "sharp": 6.0}, extra={"max_children": 9, "min_child_prior": 0.01})
+        # the in-process-model branch: Node._expand_with_legal_priors for every non-root expansion (mcts.py:227-256, 697-703)
+        for fi, sharp in ((0, 8.0), (1, 3.0), (7, 14.0)):
+            uid += 1
+            run_case("raw_legal_priors", fi, 96, 8, tt, 1234, uid, {"seed": 41 + fi, "sharp": sharp}, model_path=True)
     # repeated runs on the same board with the table on: the root is fetched from the table, visits accumulate, the
     # Dirichlet noise is applied to already-noised priors (mcts.py:342-376; tests/test_integration.py:192-236)
     uid += 1
