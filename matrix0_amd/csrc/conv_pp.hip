@@ -44,6 +44,12 @@ __device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_wave_base)
 #else
 #define PP_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+#ifndef PP_EARLY_BAR
+#define PP_EARLY_BAR 0
+#endif
+#ifndef PP_M16_ISSUE_AT
+#define PP_M16_ISSUE_AT 2
+#endif
 #ifndef PP_MFMA_REP
 #define PP_MFMA_REP 1
 #endif
@@ -60,6 +66,10 @@ __device__ unsigned long long* g_pp_trace;
     } while (0)
 #else
 #define PP_STAMP(slot) do {} while (0)
+#endif
+
+#ifdef SW_STAMP
+__device__ unsigned long long* g_pp_stamp;      // [blocks][4]: s_memtime / s_memrealtime at main-loop start and end
 #endif
 
 template <int EPI, int ACT>
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
     });
 
     // per-lane constants of the fragment reads
-    const int wfx = ((r31 >> 2) & 3) ^ half;                            // weight rows (64 B): swizzle key ^ k-half
+    const int wfx = ((4 - ((r31 >> 2) & 3)) & 3) ^ half;                // weight rows (64 B): swizzle key (pack_gemm) ^ k-half
     const int wrow_off = (wn * NT * 32 + r31) * 64;
     int prow[2], py[2], px[2];
 #pragma unroll
@@ -272,7 +282,13 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                     acc16[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga0[1], bfrag, acc16[1][n], 0, 0, 0);
                     acc16[2][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga1[0], bfrag, acc16[2][n], 0, 0, 0);
                     acc16[3][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga1[1], bfrag, acc16[3][n], 0, 0, 0);
-                    if constexpr (n == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+                    if constexpr (n == PP_M16_ISSUE_AT) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+#if PP_EARLY_BAR > 0
+                    // the phase-end barrier PP_EARLY_BAR MFMA groups before the last MFMA: its release latency then runs under
+                    // this wave's remaining MFMAs instead of leaving the matrix pipe idle (MFMAs touch no LDS: every LDS / DMA
+                    // ordering the barrier provides is unchanged)
+                    if constexpr (n == 2 * NT - 1 - PP_EARLY_BAR) { PP_FENCE(); PP_SETPRIO(0); PP_BARRIER(); PP_FENCE(); }
+#endif
                 });
 #else
                 static_for<0, 2>([&](auto u_) __attribute__((always_inline)) {
@@ -282,13 +298,18 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
                         acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga0[u], gb[u][ni], acc[0][ni], 0, 0, 0);
                         acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga1[u], gb[u][ni], acc[1][ni], 0, 0, 0);
                         if constexpr (u == 0 && ni == 2) { PP_FENCE(); issue_next(G_); PP_FENCE(); }
+#if PP_EARLY_BAR > 0
+                        if constexpr (u == 1 && ni == NT - 1 - PP_EARLY_BAR) { PP_FENCE(); PP_SETPRIO(0); PP_BARRIER(); PP_FENCE(); }
+#endif
                     });
                 });
 #endif
+#if PP_EARLY_BAR == 0
                 PP_SETPRIO(0);
                 PP_FENCE();
                 PP_BARRIER();
                 PP_FENCE();
+#endif
             });
 #else
             static_for<0, 4>([&](auto j_) __attribute__((always_inline)) {
@@ -363,8 +384,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(GemmArgs a) {
         }
     }
     };
+#ifdef SW_STAMP
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (wn == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
+#ifdef SW_STAMP
+    if (tid == 0) {
+        unsigned long long* o = g_pp_stamp + (size_t)blockIdx.x * 4;
+        o[0] = st_c0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tail refetches / fillers have landed
     if (wn == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
     // One more barrier, with every wave's vmcnt(0) before it: group 1 reaches its wait only AFTER the barrier that

@@ -32,6 +32,7 @@ struct ResBlockW {
     PackedGemm conv1, conv2;
     NormParams bn1, bn2;
     float *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
+    _Float16 *se_w1h = nullptr, *se_w2h = nullptr;   // fp16 copies for the fused tail (conv_tail16.h)
     int se_hidden = 0;
 };
 

@@ -126,9 +126,10 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
                     kk = sq * k_perm_ch + c;
                 }
                 int chunk = kk / KC, kc = kk % KC;
-                if (pp) {       // conv_pp_kernel: half-K-tiles of 320 x 32 k, 64-byte rows, chunk ^ (row>>2)&3
+                if (pp) {       // conv_pp16 / conv_pp kernels: half-K-tiles of 320 x 32 k, 64-byte rows, 16-byte chunk index
+                                // ^ ((4 - (row >> 2)) & 3): conflict-free for the 16x16x32 and the 32x32x16 fragment reads
                     const int kt = chunk * 9 + t, by = n / 320, nl = n % 320, h = kc >> 5, k32 = kc & 31;
-                    const int kx = (((k32 >> 3) ^ ((nl >> 2) & 3)) << 3) | (k32 & 7);
+                    const int kx = (((k32 >> 3) ^ ((4 - ((nl >> 2) & 3)) & 3)) << 3) | (k32 & 7);
                     p[((((size_t)kt * nblk + by) * 2 + h) * 320 + nl) * 32 + kx] = (_Float16)v;
                     continue;
                 }
@@ -281,6 +282,16 @@ int Net::finalize(std::string& err) {
                 for (int c = 0; c < C; ++c)
                     for (int j = 0; j < hd; ++j) w2t[(size_t)j * P + c] = w2->data[(size_t)c * hd + j];
                 r.se_w2 = upload_f32(w2t);
+                {   // fp16 copies for the fused tail
+                    std::vector<_Float16> h1(w1t.size()), h2(w2t.size());
+                    for (size_t i = 0; i < w1t.size(); ++i) h1[i] = (_Float16)w1t[i];
+                    for (size_t i = 0; i < w2t.size(); ++i) h2[i] = (_Float16)w2t[i];
+                    r.se_w1h = (_Float16*)dalloc(h1.size() * 2, false);
+                    r.se_w2h = (_Float16*)dalloc(h2.size() * 2, false);
+                    if (!r.se_w1h || !r.se_w2h) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+                    (void)hipMemcpy(r.se_w1h, h1.data(), h1.size() * 2, hipMemcpyHostToDevice);
+                    (void)hipMemcpy(r.se_w2h, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
+                }
                 std::vector<float> b2p(P, 0.f);
                 std::copy(b2->data.begin(), b2->data.end(), b2p.begin());
                 r.se_b2 = upload_f32(b2p);
@@ -488,7 +499,8 @@ hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Flo
     a.epi_act = act; a.out_scale = 1.f; a.w_pp = g.pp ? 1 : 0;
     a.res = x;
     if (next_bn1 && y2) { a.y2 = y2; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }
-    if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden; }
+    if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden;
+                   a.se_w1h = r.se_w1h; a.se_w2h = r.se_w2h; }
     const bool timed = profile_;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {

@@ -37,6 +37,8 @@ struct GemmArgs {
     const float* se_w2;      // [Hd][C] (transposed)
     const float* se_b2;
     int se_hidden;
+    const _Float16* se_w1h;  // fp16 copies of se_w1 / se_w2 (same layouts): conv_pp16's tail stages BOTH in LDS with one DMA
+    const _Float16* se_w2h;  //   wave (half the bytes of the f32 matrices, which it brought in one after the other)
 };
 
 struct EwArgs {

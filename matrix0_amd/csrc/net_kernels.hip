@@ -230,6 +230,7 @@ static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
 hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st);              // conv_pp.hip
+hipError_t launch_conv_pp16(const GemmArgs& a, hipStream_t st);            // conv_pp16.hip
 
 int conv_gemm_tile_n(int Cin, int Npad) {
     return (Npad % 320 == 0 && Cin % 64 == 0) ? 320 : 32;
@@ -243,7 +244,12 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     const bool big = conv_gemm_tile_n(a.Cin, a.Npad) == 320;
     if (a.gn_gamma != nullptr && !big) return hipErrorInvalidValue;   // fused GN epilogue: big tile only
     if (taps == 9) {
-        if (big) return a.w_pp ? launch_conv_pp(a, st) : hipErrorInvalidValue;
+        if (big) {
+            if (!a.w_pp) return hipErrorInvalidValue;
+            // v_mfma_f32_16x16x32_f16 main loop (conv_pp16.hip) unless M0_CONV_MFMA32=1 asks for the 32x32x16 one (A/B runs)
+            static const bool mfma32 = [] { const char* e = getenv("M0_CONV_MFMA32"); return e && e[0] == '1'; }();
+            return mfma32 ? launch_conv_pp(a, st) : launch_conv_pp16(a, st);
+        }
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
     } else if (taps == 1) {
         if (big) return a.w_pp ? hipErrorInvalidValue : launch_conv_big(a, 1, st);

@@ -4,8 +4,18 @@
 // With -DPP_TRACE it prints, for waves 0 and 4 of one workgroup and 4 consecutive K-tiles, the cycle stamps
 // L-start / L-end(before barrier) / C-start(after barrier) / C-end(MFMAs issued) of each phase.
 #include "../../matrix0_amd/csrc/conv_pp.hip"
+#include "../../matrix0_amd/csrc/conv_sw.hip"
+#include "../../matrix0_amd/csrc/conv_pp16.hip"
+#ifdef BENCH_SW
+#define launch_conv_pp launch_conv_sw
+#endif
+#ifdef BENCH_P16
+#define launch_conv_pp launch_conv_pp16
+#endif
 #include <stdio.h>
 #include <vector>
+#include <algorithm>
+#include <map>
 
 int main(int argc, char** argv) {
     const int boards = argc > 1 ? atoi(argv[1]) : 4096;
@@ -39,22 +49,109 @@ int main(int argc, char** argv) {
         hipMemcpy(dres, din, (size_t)M * C * 2, hipMemcpyDeviceToDevice);
         a.out_stats = nullptr; a.res = dres; a.y2 = dy2; a.gn_gamma = dg; a.gn_beta = dbt; a.epi_act = ACT_SILU;
         a.se_w1 = dw1; a.se_b1 = db1; a.se_w2 = dw2; a.se_b2 = db2; a.se_hidden = Hd;
+        {
+            std::vector<_Float16> h1(w1.size()), h2(w2.size());
+            for (size_t i = 0; i < w1.size(); ++i) h1[i] = (_Float16)w1[i];
+            for (size_t i = 0; i < w2.size(); ++i) h2[i] = (_Float16)w2[i];
+            _Float16 *dh1, *dh2; hipMalloc(&dh1, h1.size() * 2); hipMalloc(&dh2, h2.size() * 2);
+            hipMemcpy(dh1, h1.data(), h1.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dh2, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
+            a.se_w1h = dh1; a.se_w2h = dh2;
+        }
     }
 #endif
 #ifdef PP_TRACE
     unsigned long long* dtr; hipMalloc(&dtr, 2 * 4 * 4 * 4 * 8); hipMemset(dtr, 0, 2 * 4 * 4 * 4 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &dtr, sizeof(dtr));
 #endif
+#ifdef SW_STAMP
+    unsigned long long* dst_; hipMalloc(&dst_, (size_t)(M / 256) * 16 * 8); hipMemset(dst_, 0, (size_t)(M / 256) * 16 * 8);
+#if defined(BENCH_SW)
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sw_stamp), &dst_, sizeof(dst_));
+#elif defined(BENCH_P16)
+    hipMemcpyToSymbol(HIP_SYMBOL(g_p16_stamp), &dst_, sizeof(dst_));
+#else
+    hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stamp), &dst_, sizeof(dst_));
+#endif
+#endif
+#if defined(SW_STAMP) && defined(BENCH_P16) && defined(BENCH_TAIL)
+    unsigned long long* dtail_; hipMalloc(&dtail_, (size_t)(M / 256) * 8 * 8); hipMemset(dtail_, 0, (size_t)(M / 256) * 8 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamp), &dtail_, sizeof(dtail_));
+#endif
     hipStream_t st; hipStreamCreate(&st);
     for (int i = 0; i < 3; ++i) launch_conv_pp(a, st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, st);
-    for (int i = 0; i < iters; ++i) launch_conv_pp(a, st);
+    for (int i = 0; i < iters; ++i) { a.ksplit = i & 1; launch_conv_pp(a, st); }
     hipEventRecord(e1, st);
     hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, fl = 2.0 * M * C * C * 9.0;
     printf("conv_pp boards=%d: %.1f us/launch, %.1f TFLOP/s  (%s)\n", boards, us, fl / us / 1e6, hipGetErrorString(hipGetLastError()));
+#ifdef SW_STAMP
+    {
+        std::vector<unsigned long long> hs((size_t)(M / 256) * 4);
+        hipMemcpy(hs.data(), dst_, hs.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> cyc, clk;
+        for (int b = 0; b < M / 256; ++b) {
+            const double dc = (double)(hs[b * 4 + 2] - hs[b * 4 + 0]), dr = (double)(hs[b * 4 + 3] - hs[b * 4 + 1]);
+            cyc.push_back(dc); clk.push_back(dc / dr * 100.0);
+        }
+        std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+        printf("main loop per workgroup tile: median %.0f cycles (min %.0f max %.0f), in-kernel clock median %.0f MHz; ideal MFMA issue 115200 cycles -> %.1f %%\n",
+               cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], 100.0 * 115200.0 / cyc[cyc.size() / 2]);
+    }
+#endif
+#if defined(SW_STAMP) && defined(BENCH_P16) && defined(BENCH_TAIL)
+    {
+        const int nb = M / 256;
+        std::vector<unsigned long long> ht((size_t)nb * 8);
+        hipMemcpy(ht.data(), dtail_, ht.size() * 8, hipMemcpyDeviceToHost);
+        double d[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) for (int k = 0; k < 4; ++k) d[k] += (double)(ht[b * 8 + k + 1] - ht[b * 8 + k]);
+        printf("tail phases per workgroup (wave 0): SE gate %.2f us, stage + x loads %.2f us, y = x + t / store / stats %.2f us, y2 %.2f us\n",
+               d[0] / nb * 0.01, d[1] / nb * 0.01, d[2] / nb * 0.01, d[3] / nb * 0.01);
+    }
+#endif
+#if defined(SW_STAMP) && defined(BENCH_P16)
+    {   // per-CU timeline of the last launch: entry -> loop start -> loop end -> (before epilogue), realtime ticks of 10 ns
+        const int nb = M / 256;
+        std::vector<unsigned long long> hs((size_t)nb * 8);
+        hipMemcpy(hs.data(), dst_, hs.size() * 8, hipMemcpyDeviceToHost);
+        struct Ev { unsigned long long entry, ls, le, x; };
+        std::map<unsigned long long, std::vector<Ev>> bycu;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < nb; ++b) {
+            Ev e{hs[(size_t)nb * 4 + b * 4 + 0], hs[b * 4 + 1], hs[b * 4 + 3], hs[(size_t)nb * 4 + b * 4 + 1]};
+            const unsigned long long id = (hs[(size_t)nb * 4 + b * 4 + 3] << 32) | (hs[(size_t)nb * 4 + b * 4 + 2] & 0xffffff00ull);
+            bycu[id].push_back(e);
+            t0 = std::min(t0, e.entry); t1 = std::max(t1, e.x);
+        }
+        double pro = 0, loop = 0, gap = 0; int ng = 0, n = 0;
+        for (auto& kv : bycu) {
+            auto& v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Ev& a, const Ev& b) { return a.entry < b.entry; });
+            for (size_t i = 0; i < v.size(); ++i) {
+                pro += (double)(v[i].ls - v[i].entry); loop += (double)(v[i].le - v[i].ls); ++n;
+                if (i) { gap += (double)(v[i].entry - v[i - 1].x); ++ng; }
+            }
+        }
+        {   // idle time between the last two launches on the device's own clock
+            std::vector<unsigned long long> h2((size_t)nb * 16);
+            hipMemcpy(h2.data(), dst_, h2.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long ent[2] = {~0ull, ~0ull}, ex[2] = {0, 0};
+            for (int par = 0; par < 2; ++par)
+                for (int b = 0; b < nb; ++b) {
+                    const unsigned long long* o = h2.data() + (size_t)nb * 4 + (size_t)par * nb * 8 + b * 4;
+                    ent[par] = std::min(ent[par], o[0]); ex[par] = std::max(ex[par], o[1]);
+                }
+            const int last = (iters - 1) & 1, prev = last ^ 1;
+            printf("between the last two launches: previous exit -> last first entry %.2f us; previous span %.1f us, last span %.1f us\n",
+                   ((double)ent[last] - (double)ex[prev]) * 0.01, (ex[prev] - ent[prev]) * 0.01, (ex[last] - ent[last]) * 0.01);
+        }
+        printf("timeline: %zu CU ids, span %.1f us; per workgroup: prologue %.2f us, main loop %.2f us; gap end->next entry %.2f us (n=%d); first entry spread -> see span\n",
+               bycu.size(), (t1 - t0) * 0.01, pro / n * 0.01, loop / n * 0.01, ng ? gap / ng * 0.01 : 0.0, ng);
+    }
+#endif
 #ifdef PP_TRACE
     unsigned long long h[2 * 4 * 4 * 4];
     hipMemcpy(h, dtr, sizeof(h), hipMemcpyDeviceToHost);
