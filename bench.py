@@ -202,14 +202,17 @@ def main():
 
     cfg_dict = json.loads(json.dumps(SELFPLAY_CFG))
     cfg_dict["selfplay"]["num_simulations"] = args.sims
+    # unbounded mode (total_games=0): finished games are replaced forever, so every rank (and every pool stream) draws its
+    # game indices from its own block of 2^24 -- no (seed, index) pair is ever played twice in one run
+    first_index = rank * (1 << 24)
     cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
-                                     first_game_index=m0dist.shard_games(args.games * world, rank, world)[0], leaves_per_step=args.leaves,
+                                     first_game_index=first_index, leaves_per_step=args.leaves,
                                      virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
     if args.streams > 1:
         made = [be]
         e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
                              cfg_dict, streams=args.streams, concurrent_games=args.games, total_games=0,
-                             first_game_index=m0dist.shard_games(args.games * world, rank, world)[0], leaves_per_step=args.leaves,
+                             first_game_index=first_index, leaves_per_step=args.leaves,
                              virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
     else:
         e = eng.SelfplayEngine(be, cfg)

@@ -29,7 +29,6 @@ class M0Backend:
         if not self._h:
             raise RuntimeError(f"m0_net_create failed: {_lib.last_error()}")
         self._finalized = False
-        self._lock = threading.Lock()
         self.ssl_tasks = [t for t in _lib.SSL_ORDER if self._cfg.ssl_tasks & _lib.SSL_BITS[t]] \
             if self._cfg.self_supervised else []
 

@@ -29,6 +29,8 @@ struct m0_net {
 Net* m0_net_impl(m0_net* n) { return n ? n->net : nullptr; }
 hipStream_t m0_net_stream(m0_net* n) { return n ? n->stream : nullptr; }
 int m0_net_device(m0_net* n) { return n ? n->device : 0; }
+void m0_net_lock(m0_net* n) { if (n) n->mu.lock(); }
+void m0_net_unlock(m0_net* n) { if (n) n->mu.unlock(); }
 
 extern "C" {
 

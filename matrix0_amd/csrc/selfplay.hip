@@ -61,6 +61,7 @@ struct m0_selfplay {
     m0_selfplay_cfg cfg;
     TreeCfg tc;
     m0_net* nethandle = nullptr;
+    m0_net* nethandle_b = nullptr;
     Net* net = nullptr;
     Net* net_b = nullptr;                 // arena: the second network (games with an odd index play it as White)
     int device = 0;
@@ -75,6 +76,9 @@ struct m0_selfplay {
     float* logits_dev = nullptr;
     float* values_dev = nullptr;
     float* ssl_dev = nullptr;
+    Pos* ssl_pos_dev = nullptr;            // staging of one finished game's positions / SSL target maps (ssl_targets)
+    float* ssl_out_dev = nullptr;
+    int ssl_cap = 0;
     int* ids_dev = nullptr;
     int* slots_dev = nullptr;
     std::deque<GameRecordOwner*> done_records;
@@ -252,16 +256,13 @@ void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool ha
         if (c.ssl_targets && (int)hgm.rec_pos.size() == hgm.nstates) {
             // targets for all plies of the game in one launch on the engine stream
             const int T = hgm.nstates;
-            Pos* dp = nullptr; float* dout = nullptr;
-            if (hipMalloc((void**)&dp, sizeof(Pos) * T) == hipSuccess && hipMalloc((void**)&dout, (size_t)T * 17 * 64 * 4) == hipSuccess) {
+            if (T <= sp->ssl_cap && sp->ssl_pos_dev && sp->ssl_out_dev) {      // buffers allocated once per engine
                 o->ssl.resize((size_t)T * 17 * 64);
-                (void)hipMemcpyAsync(dp, hgm.rec_pos.data(), sizeof(Pos) * T, hipMemcpyHostToDevice, sp->stream);
-                (void)launch_ssl_targets(dp, T, dout, sp->stream);
-                (void)hipMemcpyAsync(o->ssl.data(), dout, (size_t)T * 17 * 64 * 4, hipMemcpyDeviceToHost, sp->stream);
+                (void)hipMemcpyAsync(sp->ssl_pos_dev, hgm.rec_pos.data(), sizeof(Pos) * T, hipMemcpyHostToDevice, sp->stream);
+                (void)launch_ssl_targets(sp->ssl_pos_dev, T, sp->ssl_out_dev, sp->stream);
+                (void)hipMemcpyAsync(o->ssl.data(), sp->ssl_out_dev, (size_t)T * 17 * 64 * 4, hipMemcpyDeviceToHost, sp->stream);
                 (void)hipStreamSynchronize(sp->stream);
             }
-            if (dp) (void)hipFree(dp);
-            if (dout) (void)hipFree(dout);
         }
         m0_game_record r;
         memset(&r, 0, sizeof(r));
@@ -290,9 +291,12 @@ void finish_search(m0_selfplay* sp, int slot, std::vector<int>& adv_ids, std::ve
     long total = 0;
     int maxv = 0;
     for (int i = 0; i < k; ++i) { total += R.child_n[i]; if (R.child_n[i] > maxv) maxv = R.child_n[i]; }
-    if (k <= 0 || total <= 0) {        // mcts.py:435-463 raises RuntimeError; the engine drops the game loudly
-        sp->stats.arena_overflows++;
-        finish_game(sp, slot, false, 0, false, 0.f);
+    if (k <= 0 || total <= 0) {        // mcts.py:435-463 raises RuntimeError: the game is dropped (no record), counted
+        sp->stats.arena_overflows++;   // in stats.arena_overflows, which the worker logs
+        hgm.nstates = 0;               // no rows -> finish_game emits no training record
+        hgm.states.clear(); hgm.pis.clear(); hgm.masks.clear(); hgm.search_values.clear(); hgm.turns.clear();
+        hgm.sims_used.clear(); hgm.rec_pos.clear();
+        finish_game(sp, slot, false, 0, true, 0.f);
         return;
     }
     const double root_q = R.root_n > 0 ? R.root_q : g.root_v;
@@ -388,15 +392,19 @@ int one_step(m0_selfplay* sp, std::string& err) {
     if (rows > sp->rows_max || sp->rows2[1] > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
     if (rows > 0) {
         if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
+        m0_net_lock(sp->nethandle);          // an infer_np on the same backend from another thread waits here
         int rc = sp->net->forward(nullptr, sp->d.x0, rows, sp->logits_dev, sp->values_dev,
                                   sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr, sp->stream, err);
+        m0_net_unlock(sp->nethandle);
         if (rc != M0_OK) return rc;
     }
     if (sp->rows2[1] > 0) {                 // arena: the other network's leaves, in their own region of the batch
         if (!sp->net_b) { err = "rows for a second network without one"; return M0_ERR_STATE; }
         const size_t b = (size_t)sp->d.net_row_base;
+        m0_net_lock(sp->nethandle_b);
         int rc = sp->net_b->forward(nullptr, sp->d.x0 + b * 64 * 32, sp->rows2[1], sp->logits_dev + b * 4672,
                                     sp->values_dev + b, nullptr, sp->stream, err);
+        m0_net_unlock(sp->nethandle_b);
         if (rc != M0_OK) return rc;
         rows += sp->rows2[1];
     }
@@ -508,6 +516,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->cfg = *cfg;
     fill_tree_cfg(*cfg, sp->tc);
     sp->nethandle = nh;
+    sp->nethandle_b = nh_b;
     sp->net = m0_net_impl(nh);
     sp->net_b = m0_net_impl(nh_b);
     sp->cfg.arena_mode = nh_b ? 1 : 0;
@@ -558,6 +567,11 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->d.net_row_base = sp->rows_max;
     if (cfg->ssl_in_forward && sp->net && sp->net->ssl_channels_total() > 0)
         sp->ssl_dev = dalloc<float>(sp, (size_t)sp->rows_max * sp->net->ssl_channels_total() * 64);
+    if (cfg->ssl_targets) {
+        sp->ssl_cap = cfg->max_game_len > 0 ? cfg->max_game_len + 1 : 513;
+        sp->ssl_pos_dev = dalloc<Pos>(sp, sp->ssl_cap);
+        sp->ssl_out_dev = dalloc<float>(sp, (size_t)sp->ssl_cap * 17 * 64);
+    }
     sp->ids_dev = dalloc<int>(sp, sp->G);
     sp->slots_dev = dalloc<int>(sp, sp->G);
     sp->d.logits = sp->logits_dev; sp->d.values = sp->values_dev;

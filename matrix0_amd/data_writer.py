@@ -95,9 +95,10 @@ class ReplayShardWriter(SelfplayShardWriter):
         self.backups_dir.mkdir(parents=True, exist_ok=True)
         self.max_shards = int(max_shards)
         self.shard_size = int(shard_size)
-        self._buf = {"s": [], "pi": [], "z": [], "legal_mask": []}
+        self._buf = {"s": [], "pi": [], "z": [], "legal_mask": [], "_has_mask": []}
         self._count = 0
-        self._mask_ok = True            # legal_mask is written only if no buffered game lacks it (reference: concat or drop)
+        # legal_mask is decided per flushed shard: written iff every row of that shard came from a game that carried one
+        # (the reference concatenates the masks of a shard's games or drops the key for that shard)
         self.summary = {"games": 0, "moves": 0, "resigned": 0, "draws": 0, "entropy": 0.0, "avg_sims": 0.0}
         self.written = []
 
@@ -108,10 +109,10 @@ class ReplayShardWriter(SelfplayShardWriter):
             raise ValueError("s / pi / z row counts differ")
         self._buf["s"].append(s); self._buf["pi"].append(pi); self._buf["z"].append(z)
         lm = data.get("legal_mask")
-        if lm is not None and np.asarray(lm).shape[0] == s.shape[0]:
-            self._buf["legal_mask"].append(np.asarray(lm))
-        else:
-            self._mask_ok = False
+        have = lm is not None and np.asarray(lm).shape[0] == s.shape[0]
+        self._buf["legal_mask"].append(np.asarray(lm).reshape(s.shape[0], -1).astype(np.uint8, copy=False) if have
+                                       else np.zeros((s.shape[0], pi.shape[1]), np.uint8))
+        self._buf["_has_mask"].append(np.full(s.shape[0], have, dtype=bool))
         self._count += int(s.shape[0])
         g = self.summary
         g["games"] += 1
@@ -149,16 +150,13 @@ class ReplayShardWriter(SelfplayShardWriter):
 
     # -- internals ------------------------------------------------------------------------------------------------
     def _flush(self, take: int) -> None:
-        cat = {k: np.concatenate(v, axis=0) for k, v in self._buf.items() if v and (k != "legal_mask" or self._mask_ok)}
+        cat = {k: np.concatenate(v, axis=0) for k, v in self._buf.items() if v}
         payload = {"s": cat["s"][:take], "pi": cat["pi"][:take], "z": cat["z"][:take]}
-        if "legal_mask" in cat:
+        if bool(cat["_has_mask"][:take].all()):
             payload["legal_mask"] = cat["legal_mask"][:take].astype(np.uint8, copy=False)
-        for k in ("s", "pi", "z"):
+        for k in ("s", "pi", "z", "legal_mask", "_has_mask"):
             self._buf[k] = [cat[k][take:]]
-        self._buf["legal_mask"] = [cat["legal_mask"][take:]] if "legal_mask" in cat else []
         self._count -= take
-        if self._count == 0:
-            self._mask_ok = True
         self.written.append(self._write_shard(payload, self.replays_dir, "selfplay"))
 
     def _write_shard(self, data: Dict[str, np.ndarray], dir_path: Path, source: str) -> str:

@@ -21,26 +21,41 @@ def shard_games(total_games: int, rank: int, world: int) -> Tuple[int, int]:
     return first, n
 
 
+def is_gemm_weight(name: str, shape) -> bool:
+    """Tensors the engine packs as fp16 MFMA operands (csrc/net.hip pack_gemm / pack_attn_block): conv and fully
+    connected weight matrices.  Everything else (norm gains and biases, squeeze-excite, positional encoding, relative
+    position bias, the logit scale) is consumed in fp32."""
+    return name.endswith(".weight") and len(shape) >= 2 and ".se_fc" not in name
+
+
 def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], model_cfg: dict, src: int = 0,
                          device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
-    """Rank `src` holds the state dict (fp32); every rank returns an identical copy.  One flat fp32 blob
-    (230 MB for R24-320) in a single broadcast: on xGMI a ring/tree broadcast of that size is ~ms."""
+    """Rank `src` holds the state dict; every rank returns the same tensors.  Two flat blobs in two broadcasts: the GEMM
+    weights as fp16 -- exactly the values the kernels compute with, 114 MB for R24-320 -- and the small fp32 remainder
+    (0.5 MB).  With backend "nccl" the blobs live on the GPU and move over xGMI (RCCL); the engine's weight loader takes
+    host memory (m0_net_load_weight), so each rank copies its blob down once afterwards."""
     shapes = param_shapes(model_cfg)
     names = list(shapes.keys())
-    sizes = [int(np.prod(shapes[k])) if len(shapes[k]) else 1 for k in names]
+    half = [k for k in names if is_gemm_weight(k, shapes[k])]
+    full = [k for k in names if not is_gemm_weight(k, shapes[k])]
+    numel = {k: (int(np.prod(shapes[k])) if len(shapes[k]) else 1) for k in names}
     dev = device if device is not None else torch.device("cpu")
-    blob = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    blob16 = torch.empty(sum(numel[k] for k in half), dtype=torch.float16, device=dev)
+    blob32 = torch.empty(sum(numel[k] for k in full), dtype=torch.float32, device=dev)
     if dist.get_rank() == src:
         if sd is None:
             raise ValueError("source rank needs the state dict")
-        blob.copy_(torch.cat([sd[k].reshape(-1).float() for k in names]).to(dev))
-    dist.broadcast(blob, src=src)
-    flat = blob.cpu()
-    out, off = {}, 0
-    for k, n in zip(names, sizes):
-        out[k] = flat[off:off + n].reshape(shapes[k]).clone()
-        off += n
-    return out
+        blob16.copy_(torch.cat([sd[k].reshape(-1).half() for k in half]).to(dev))
+        blob32.copy_(torch.cat([sd[k].reshape(-1).float() for k in full]).to(dev))
+    dist.broadcast(blob16, src=src)
+    dist.broadcast(blob32, src=src)
+    out = {}
+    for blob, keys in ((blob16.cpu().float(), half), (blob32.cpu(), full)):
+        off = 0
+        for k in keys:
+            out[k] = blob[off:off + numel[k]].reshape(shapes[k]).clone()
+            off += numel[k]
+    return {k: out[k] for k in names}
 
 
 def reduce_clock_and_counters(seconds: float, counters: np.ndarray, device: Optional[torch.device] = None):

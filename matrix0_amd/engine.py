@@ -332,7 +332,8 @@ class SelfplayPool:
                 cfg = selfplay_cfg_from_dict(cfg_dict, concurrent_games=(min(per[i], tot[i]) if total_games > 0 else per[i]) or 1,
                                              total_games=tot[i], first_game_index=first, **cfg_kw)
                 self.engines.append(SelfplayEngine(be, cfg))
-                first += tot[i] if total_games > 0 else per[i]
+                # unbounded mode: each engine restarts games forever, so it gets a disjoint block of indices
+                first += tot[i] if total_games > 0 else (1 << 20)
         except Exception:
             self.close()
             raise

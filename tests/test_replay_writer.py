@@ -65,3 +65,27 @@ def test_direct_emission_mask_dropped_if_any_game_lacks_it_and_pruning(tmp_path)
     # only the newest max_shards replay shards survive (created_at ties are broken arbitrarily: count only)
     left = list((tmp_path / "replays").glob("*.npz"))
     assert len(left) == 2 and len(_rows(tmp_path)) == 2
+
+
+def test_legal_mask_is_decided_per_shard(tmp_path):
+    """A game without legal_mask must not cost later shards theirs: the key is dropped only from the shard(s) that
+    contain rows of that game (round-1 advisor finding)."""
+    from matrix0_amd.data_writer import ReplayShardWriter
+    w = ReplayShardWriter(base_dir=str(tmp_path), shard_size=64, max_shards=100)
+
+    def game(n, with_mask, tag):
+        g = {"s": np.full((n, 19, 8, 8), tag, np.float32), "pi": np.full((n, 4672), 1.0 / 4672, np.float32),
+             "z": np.zeros(n, np.float32)}
+        if with_mask:
+            g["legal_mask"] = np.ones((n, 4672), np.uint8)
+        return g
+
+    w.add_game(game(10, False, 1.0))          # mask-less rows land in shard 0
+    for k in range(4):
+        w.add_game(game(50, True, 2.0 + k))   # 200 masked rows: shards 0..2 full, 18 rows left
+    w.close()
+    shards = [np.load(p) for p in w.written]
+    assert [int(s["s"].shape[0]) for s in shards] == [64, 64, 64, 18]
+    assert "legal_mask" not in shards[0].files
+    for s in shards[1:]:
+        assert "legal_mask" in s.files and s["legal_mask"].shape == (s["s"].shape[0], 4672) and s["legal_mask"].all()

@@ -6,7 +6,7 @@ import json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import numpy as np
-from oracle import net_ref
+from matrix0_amd.weights import random_state_dict
 from matrix0_amd.backend import M0Backend
 from matrix0_amd import engine as eng
 import bench
@@ -14,7 +14,7 @@ import bench
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1000.0
-be = M0Backend.from_state_dict(bench.R24_320, net_ref.random_state_dict(bench.R24_320, seed=0))
+be = M0Backend.from_state_dict(bench.R24_320, random_state_dict(bench.R24_320, seed=0, varied=True))
 cfg = eng.selfplay_cfg_from_dict(bench.SELFPLAY_CFG, concurrent_games=games, total_games=games, leaves_per_step=leaves,
                                  virtual_loss_active=True, record_games=True)
 e = eng.SelfplayEngine(be, cfg)
