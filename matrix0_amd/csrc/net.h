@@ -128,6 +128,7 @@ private:
     int wsB_ = 0, wsM_ = 0;
     _Float16 *X0_ = nullptr, *XA_ = nullptr, *XB_ = nullptr, *T1_ = nullptr, *T2_ = nullptr, *QKV_ = nullptr,
              *O_ = nullptr, *AA_ = nullptr;
+    const NormParams* tx_next_ = nullptr;   // set by forward() right before a conv1 launch that reads the raw stream (run_gemm)
     float *SX_ = nullptr, *S1_ = nullptr, *S2_ = nullptr, *G_ = nullptr;   // G_: squeeze-excite gates [B][C]
     _Float16 *PH_ = nullptr, *PH2_ = nullptr, *VH_ = nullptr, *VH2_ = nullptr, *F1_ = nullptr, *F2_ = nullptr,
              *F3_ = nullptr, *F4_ = nullptr, *SH_ = nullptr, *SH2_ = nullptr, *SO_ = nullptr;

@@ -459,6 +459,10 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
     a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale; a.w_pp = g.pp ? 1 : 0;
+    if (tx_next_) {                   // GroupNorm-on-load: `in` is the raw residual stream (set by forward() for this launch only)
+        a.tx_table = SX_;
+        tx_next_ = nullptr;
+    }
     const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {
@@ -499,6 +503,7 @@ hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Flo
     a.epi_act = act; a.out_scale = 1.f; a.w_pp = g.pp ? 1 : 0;
     a.res = x;
     if (next_bn1 && y2) { a.y2 = y2; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }
+    else if (next_bn1 && !y2) { a.out_gn = SX_; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }   // GroupNorm-on-load
     if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden;
                    a.se_w1h = r.se_w1h; a.se_w2h = r.se_w2h; }
     const bool timed = profile_;
@@ -564,6 +569,14 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
                            (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
     const char* faenv = getenv("M0_FUSE_ATTN");          // =0: qkv GEMM + attn_core + proj GEMM + ew_board as separate kernels
     const bool fuse_attn = C == 320 && !(faenv && faenv[0] == '0');
+    // GroupNorm-on-load (M0_CONV_TX=1, off by default): the tail / attention kernels store the raw residual stream y plus a
+    // (scale, shift) table per (board, channel) and conv1 of the next block normalises + activates its activation tiles in LDS --
+    // the pre-activated copy y2 (84 MB per block at 4096 boards) is never written.  Measured: the tail gets 31 us shorter, conv1
+    // 45 us longer (conv_pp16.hip), so the y2 path stays the default.
+    const char* txenv = getenv("M0_CONV_TX");
+    const char* m32env = getenv("M0_CONV_MFMA32");
+    const bool tx_on = fuse_tail && fuse_attn && C == 320 && (txenv && txenv[0] == '1') && !(m32env && m32env[0] == '1');
+    bool stats_ready = false;          // SX_ holds the statistics of the current stream xa
     // ew: elementwise glue; y2/gn2 = pre-activated input of the NEXT residual block (its bn1), or null
     auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
                   const float* pos, const NormParams* ln, _Float16* y, float* ost, const NormParams* next_bn1,
@@ -631,7 +644,8 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             ia.Mrows = Mc; ia.Mvalid = Mc; ia.Cin = inter_.Cin; ia.N = inter_.N; ia.Npad = inter_.N; ia.ldo = inter_.N;
             ia.epi_act = act; ia.out_scale = 1.f; ia.w_pp = inter_.pp ? 1 : 0;
             ia.res = xa; ia.pre_gamma = inter_n_.gamma; ia.pre_beta = inter_n_.beta;
-            if (first_bn1) { ia.y2 = AA_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; }
+            if (first_bn1 && tx_on) { ia.out_gn = SX_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; stats_ready = true; }
+            else if (first_bn1) { ia.y2 = AA_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; }
             KCHK(launch_conv_gemm(ia, 9, st));
         } else {
             KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
@@ -649,14 +663,16 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             // pre-activation block (resnet.py:45-51): AA_ = act(GN1(x)) comes from the previous ew; conv1's
             // epilogue applies GN2+act in registers (big tile) so conv2 also reads a ready operand
             if (big) {
-                KCHK(run_gemm(r.conv1, AA_, T1_, Mc, Mc, &r.bn2, act, nullptr, nullptr, false, 1.f, st));
+                if (tx_on && stats_ready) tx_next_ = &r.bn1;          // conv1 reads the raw stream and applies bn1 + act itself
+                KCHK(run_gemm(r.conv1, (tx_on && stats_ready) ? xa : AA_, T1_, Mc, Mc, &r.bn2, act, nullptr, nullptr, false, 1.f, st));
             } else {
                 KCHK(run_gemm(r.conv1, AA_, T2_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
                 KCHK(ew(T2_, S1_, &r.bn2, nullptr, nullptr, nullptr, nullptr, T1_, nullptr, nullptr, nullptr, C, Bp));
             }
             if (fuse_tail) {
                 // conv2 + squeeze-excite + residual add + the next block's GroupNorm/activation in one kernel
-                KCHK(run_conv_tail(r, T1_, xa, xb, next_bn1_after(li), AA_, act, Mc, st));
+                KCHK(run_conv_tail(r, T1_, xa, xb, next_bn1_after(li), tx_on ? nullptr : AA_, act, Mc, st));
+                stats_ready = tx_on && next_bn1_after(li) != nullptr;
             } else {
                 KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, nullptr, 0, nullptr, S2_, false, 1.f, st));
                 KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
@@ -671,7 +687,10 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
                 memset(&ab, 0, sizeof(ab));
                 ab.x = xa; ab.wpack = w.blk_w; ab.bias = w.blk_bias; ab.mask = mask_dev_;
                 ab.ln_g = w.ln.gamma; ab.ln_b = w.ln.beta; ab.y = xb;
-                if (const NormParams* nb = next_bn1_after(li)) { ab.y2 = AA_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; }
+                if (const NormParams* nb = next_bn1_after(li)) {
+                    if (tx_on) { ab.out_gn = SX_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; stats_ready = true; }
+                    else { ab.y2 = AA_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; }
+                }
                 ab.B = Bp; ab.ln_count = C_; ab.act = act; ab.mix = cfg_.attention_unmasked_mix;
                 ab.inv_sqrt_d = 1.f / sqrtf((float)(C_ / cfg_.attention_heads));
                 KCHK(launch_attn_block(ab, st));

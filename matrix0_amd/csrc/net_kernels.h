@@ -37,6 +37,13 @@ struct GemmArgs {
     const float* se_w2;      // [Hd][C] (transposed)
     const float* se_b2;
     int se_hidden;
+    // GroupNorm-on-load (conv_pp16_kernel, conv1 of a residual block): the producer of `in` stored the RAW residual stream y
+    // and, per (board, channel), the (scale, shift) of the next block's GroupNorm16 -- scale = rstd * gamma, shift = beta -
+    // mean * scale -- in out_gn [Mrows/64][320][2]; the consumer brings its 4 boards' table into LDS with the prologue DMA and
+    // applies act(y * scale + shift) to the activation tiles in LDS right after they land: the pre-activated copy y2 of the
+    // stream (84 MB per block at 4096 boards) is never written to HBM.
+    float* out_gn;           // producer (tail epilogues): the table instead of y2 (y2 null; gn_gamma / gn_beta = the NEXT bn1)
+    const float* tx_table;   // consumer: [Mrows/64][320][2] for `in`; null = `in` is already activated
     const _Float16* se_w1h;  // fp16 copies of se_w1 / se_w2 (same layouts): conv_pp16's tail stages BOTH in LDS with one DMA
     const _Float16* se_w2h;  //   wave (half the bytes of the f32 matrices, which it brought in one after the other)
 };
@@ -94,6 +101,7 @@ struct AttnBlockArgs {
     const float* gn2_beta;
     _Float16* y;             // [B][64][320] LayerNorm(x + attention(x))
     _Float16* y2;            // [B][64][320] or null
+    float* out_gn;           // with y2 == null: [B][320][2] (scale, shift) of GroupNorm16(y; gn2_*) per channel (GroupNorm-on-load)
     int B;                   // boards, even
     int ln_count;            // real channel count of the LayerNorm
     int act;                 // ACT_SILU / ACT_RELU (y2)

@@ -168,6 +168,30 @@ def test_fused_attention_block_matches_split_kernels(monkeypatch):
         be.close()
 
 
+def test_groupnorm_on_load_variant_matches_default_path(monkeypatch):
+    """M0_CONV_TX=1: the tail / attention kernels emit a (scale, shift) table instead of the pre-activated copy of the stream
+    and conv1 normalises its activation tiles in LDS (conv_pp16.hip).  Same arithmetic with one fp16 rounding moved; kept
+    correct although it measured slower than the default."""
+    from matrix0_amd.backend import M0Backend
+    cfg = dict(_r24_cfg(), blocks=6)
+    sd = net_ref.random_state_dict(cfg, seed=8)
+    be = M0Backend.from_state_dict(cfg, sd)
+    g = torch.Generator().manual_seed(14)
+    B = 22
+    x = torch.zeros(B, 19, 8, 8)
+    x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+    x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+    x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+    monkeypatch.setenv("M0_CONV_TX", "0")
+    p0, v0 = be.infer_np(x.numpy())
+    monkeypatch.setenv("M0_CONV_TX", "1")
+    p1, v1 = be.infer_np(x.numpy())
+    assert np.abs(p1 - p0).max() <= 2e-3 and np.abs(v1 - v0).max() <= 2e-3
+    assert not np.array_equal(p1, p0)                       # the switch really took the other path
+    p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
+    _check("gn_on_load", p1, v1, p_ref.numpy(), v_ref.numpy())
+
+
 def test_shipped_config_288x22_zero_padded_trunk():
     """The reference's shipped config.yaml network (288 channels x 22 blocks, 18 heads, rank-160 policy, attention
     stride 2, leaky value head): the engine zero-pads its trunk to 320 channels so it runs on the MFMA big-tile kernels;
