@@ -1,0 +1,118 @@
+// Output epilogues of conv_zs_kernel (conv_zs.hip): a wave holds TWO boards x 80 channels as 8 x 5 accumulator tiles of
+// v_mfma_f32_16x16x32_f16.  M-tile mi = board row y = mi of both boards (8 squares of board a, 8 of board b), so lane
+// l = (c15 = l & 15, q = l >> 4) holds, in register r of tile (mi, ni),
+//     board  q >> 1  (of the wave's pair),   square  8 mi + 4 (q & 1) + r,   channel  16 ni + c15  (of the wave's quarter).
+// Finished values go as fp16 into the wave's private LDS image [64 squares][2 boards][80 channels] (320-byte rows, the two
+// boards side by side) and leave it as 160-byte row runs; a GroupNorm group (16 channels x 64 squares of one board) is one
+// channel tile ni of the 32 lanes with the same q >> 1.
+#pragma once
+#include "conv_epilogue.h"
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// Lanes l and l^1 (adjacent channels) exchange two values so that the even lane owns squares +0 / +2 and the odd lane squares
+// +1 / +3 of a channel PAIR: two ds_write_b32 per tile.
+__device__ __forceinline__ char* zs_stage_base(char* img, int lane) {
+    const int q = lane >> 4;
+    return img + ((q & 1) * 4 + (lane & 1)) * 320 + (q >> 1) * 160 + ((lane & 15) >> 1) * 4;
+}
+template <int MI, int NI>
+__device__ __forceinline__ void zs_stage_tile(const float (&v)[4], char* wbase, int lane) {
+    const bool odd = (lane & 1) != 0;
+    static_for<0, 2>([&](auto p_) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_)::value;                     // square pair: 2p (even lane) and 2p + 1 (odd lane)
+        const float mine = odd ? v[2 * p + 1] : v[2 * p];
+        const float send = odd ? v[2 * p] : v[2 * p + 1];
+        const float recv = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+        const half2v h = {(_Float16)(odd ? recv : mine), (_Float16)(odd ? mine : recv)};
+        *reinterpret_cast<half2v*>(wbase + (MI * 8 + 2 * p) * 320 + NI * 32) = h;
+    });
+}
+
+// sum over the 32 lanes that hold one board (same q >> 1)
+__device__ __forceinline__ float zs_sum_board(float v) {
+#pragma unroll
+    for (int o = 1; o <= 16; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// image -> global: unit u = it * 64 + lane = (square, board, 16-byte chunk of the 80 channels); 160-byte row runs.
+// `out` = first row of the wave's board pair, first channel of its quarter.
+__device__ __forceinline__ void zs_stage_flush(char* out, uint32_t ldo2, int rows_valid, const char* img, int lane) {
+    int sq = lane / 20, c20 = lane - sq * 20;
+#pragma unroll
+    for (int it = 0; it < 20; ++it) {
+        const uint4 v = *reinterpret_cast<const uint4*>(img + (it * 64 + lane) * 16);
+        const int bd = c20 >= 10 ? 1 : 0;
+        const int row = bd * 64 + sq;
+        if (row < rows_valid) *reinterpret_cast<uint4*>(out + ((uint32_t)row * ldo2 + (uint32_t)(c20 - 10 * bd) * 16u)) = v;
+        c20 += 4; sq += 3;                                          // 64 = 3 * 20 + 4
+        if (c20 >= 20) { c20 -= 20; sq += 1; }
+    }
+}
+
+// EPI 0: bias / activation ACT / scale, fp16 store, per-(board, channel) sum and sum of squares.
+// EPI 1: GroupNorm(16 channels x 64 squares) + activation ACT in registers.
+// wp = board pair of the 4-board tile, wn = channel quarter.
+template <int EPI, int ACT>
+__device__ __forceinline__ void zs_tile_epilogue(float4v (&acc)[8][5], const GemmArgs& a, char* img, int m0, int n0, int wp,
+                                                 int wn, int lane) {
+    const int c15 = lane & 15, q = lane >> 4;
+    const int colbase = n0 + wn * 80 + c15;
+    char* wbase = zs_stage_base(img, lane);
+    char* out = reinterpret_cast<char*>(a.out) + ((size_t)(m0 + wp * 128) * a.ldo + n0 + wn * 80) * 2;
+    const int rows_valid = a.Mvalid - (m0 + wp * 128);
+    if constexpr (EPI == 1) {
+        static_for<0, 5>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            const int col = colbase + ni * 16;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 8>([&](auto mi_) __attribute__((always_inline)) {
+                const float4v av = acc[decltype(mi_)::value][ni];
+                static_for<0, 4>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+            });
+            s = zs_sum_board(s); ss = zs_sum_board(ss);
+            const float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
+            const float sh = a.gn_beta[col] - mean * g;
+            static_for<0, 8>([&](auto mi_) __attribute__((always_inline)) {
+                constexpr int mi = decltype(mi_)::value;
+                float v[4];
+                static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    v[r] = act_fast<ACT>(acc[mi][ni][r] * g + sh);
+                });
+                zs_stage_tile<mi, ni>(v, wbase, lane);
+            });
+        });
+        zs_stage_flush(out, (uint32_t)a.ldo * 2u, rows_valid, img, lane);
+    }
+    if constexpr (EPI == 0) {
+        const float oscale = a.out_scale;
+        const bool want_stats = a.out_stats != nullptr;
+        float* stats = a.out_stats + ((size_t)(m0 / 64 + 2 * wp + (q >> 1)) * a.N + colbase) * 2;
+        static_for<0, 5>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            const float bias = a.bias != nullptr ? a.bias[colbase + ni * 16] : 0.f;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 8>([&](auto mi_) __attribute__((always_inline)) {
+                constexpr int mi = decltype(mi_)::value;
+                float v[4];
+                static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    v[r] = act_fast<ACT>(acc[mi][ni][r] + bias) * oscale;
+                    s += v[r]; ss += v[r] * v[r];
+                });
+                zs_stage_tile<mi, ni>(v, wbase, lane);
+            });
+            if (want_stats) {
+                s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+                if ((q & 1) == 0) { stats[ni * 32] = s; stats[ni * 32 + 1] = ss; }
+            }
+        });
+        zs_stage_flush(out, (uint32_t)a.ldo * 2u, rows_valid, img, lane);
+    }
+}

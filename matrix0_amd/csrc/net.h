@@ -33,6 +33,7 @@ struct ResBlockW {
     NormParams bn1, bn2;
     float *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
     _Float16 *se_w1h = nullptr, *se_w2h = nullptr;   // fp16 copies for the fused tail (conv_tail16.h)
+    void* se_wf = nullptr;                           // fp16 MFMA fragment pieces for conv_zs_kernel's tail (conv_zs_tail.h)
     int se_hidden = 0;
 };
 

@@ -292,6 +292,31 @@ int Net::finalize(std::string& err) {
                     (void)hipMemcpy(r.se_w1h, h1.data(), h1.size() * 2, hipMemcpyHostToDevice);
                     (void)hipMemcpy(r.se_w2h, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
                 }
+                if (P == 320 && hd <= 96) {
+                    // conv_zs_kernel's tail runs the two FCs on the matrix cores: B-fragment pieces of v_mfma_f32_16x16x32_f16,
+                    // lane (c15 = lane & 15, q = lane >> 4) holds column c15, k = 8q..8q+7 of its tile (conv_zs_tail.h):
+                    //   W1 piece (nt, ks):   W1[channel 32 ks + 8 q + e][hidden 16 nt + c15]     nt < ceil(hd/16), ks < 10
+                    //   W2 piece (nt, ks):   W2[hidden 32 ks + 8 q + e][channel 16 nt + c15]     nt < 20, ks < ceil(hd/32)
+                    const int NT1 = (hd + 15) / 16, KS2 = (hd + 31) / 32;
+                    std::vector<_Float16> wf((size_t)(10 * NT1 + 20 * KS2) * 512, (_Float16)0.f);
+                    for (int nt = 0; nt < NT1; ++nt)
+                        for (int ks = 0; ks < 10; ++ks)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int c = 32 * ks + 8 * (l >> 4) + e, j = 16 * nt + (l & 15);
+                                    if (j < hd) wf[((size_t)(nt * 10 + ks) * 64 + l) * 8 + e] = (_Float16)w1t[(size_t)c * hd + j];
+                                }
+                    for (int nt = 0; nt < 20; ++nt)
+                        for (int ks = 0; ks < KS2; ++ks)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int j = 32 * ks + 8 * (l >> 4) + e, c = 16 * nt + (l & 15);
+                                    if (j < hd) wf[((size_t)(10 * NT1 + nt * KS2 + ks) * 64 + l) * 8 + e] = (_Float16)w2t[(size_t)j * P + c];
+                                }
+                    r.se_wf = dalloc(wf.size() * 2, false);
+                    if (!r.se_wf) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+                    (void)hipMemcpy(r.se_wf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice);
+                }
                 std::vector<float> b2p(P, 0.f);
                 std::copy(b2->data.begin(), b2->data.end(), b2p.begin());
                 r.se_b2 = upload_f32(b2p);
@@ -505,7 +530,7 @@ hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Flo
     if (next_bn1 && y2) { a.y2 = y2; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }
     else if (next_bn1 && !y2) { a.out_gn = SX_; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }   // GroupNorm-on-load
     if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden;
-                   a.se_w1h = r.se_w1h; a.se_w2h = r.se_w2h; }
+                   a.se_w1h = r.se_w1h; a.se_w2h = r.se_w2h; a.se_wf = r.se_wf; }
     const bool timed = profile_;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {

@@ -46,6 +46,7 @@ struct GemmArgs {
     const float* tx_table;   // consumer: [Mrows/64][320][2] for `in`; null = `in` is already activated
     const _Float16* se_w1h;  // fp16 copies of se_w1 / se_w2 (same layouts): conv_pp16's tail stages BOTH in LDS with one DMA
     const _Float16* se_w2h;  //   wave (half the bytes of the f32 matrices, which it brought in one after the other)
+    const void* se_wf;       // conv_zs_kernel's tail: W1 and W2 as fp16 MFMA B-fragment pieces of 1 KiB (conv_zs_tail.h; net.hip packs)
 };
 
 struct EwArgs {

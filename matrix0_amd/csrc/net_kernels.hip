@@ -231,6 +231,8 @@ static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
 hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st);              // conv_pp.hip
 hipError_t launch_conv_pp16(const GemmArgs& a, hipStream_t st);            // conv_pp16.hip
+hipError_t launch_conv_zs(const GemmArgs& a, hipStream_t st);              // conv_zs.hip
+bool conv_zs_supports(const GemmArgs& a);
 
 int conv_gemm_tile_n(int Cin, int Npad) {
     return (Npad % 320 == 0 && Cin % 64 == 0) ? 320 : 32;
@@ -248,7 +250,12 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
             if (!a.w_pp) return hipErrorInvalidValue;
             // v_mfma_f32_16x16x32_f16 main loop (conv_pp16.hip) unless M0_CONV_MFMA32=1 asks for the 32x32x16 one (A/B runs)
             static const bool mfma32 = [] { const char* e = getenv("M0_CONV_MFMA32"); return e && e[0] == '1'; }();
-            return mfma32 ? launch_conv_pp(a, st) : launch_conv_pp16(a, st);
+            if (mfma32) return launch_conv_pp(a, st);
+            // conv_zs_kernel: the same loop with the wave tile laid out so that the M-tiles that only see the zero padding above /
+            // below the board are skipped (8.3 % of the MFMAs); M0_CONV_ZS=0 keeps conv_pp16_kernel (A/B runs)
+            const char* zs = getenv("M0_CONV_ZS");
+            if (!(zs && zs[0] == '0') && conv_zs_supports(a)) return launch_conv_zs(a, st);
+            return launch_conv_pp16(a, st);
         }
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);
     } else if (taps == 1) {

@@ -6,6 +6,10 @@
 #include "../../matrix0_amd/csrc/conv_pp.hip"
 #include "../../matrix0_amd/csrc/conv_sw.hip"
 #include "../../matrix0_amd/csrc/conv_pp16.hip"
+#include "../../matrix0_amd/csrc/conv_zs.hip"
+#ifdef BENCH_ZS
+#define launch_conv_pp launch_conv_zs
+#endif
 #ifdef BENCH_SW
 #define launch_conv_pp launch_conv_sw
 #endif
@@ -70,6 +74,19 @@ int main(int argc, char** argv) {
             _Float16 *dh1, *dh2; hipMalloc(&dh1, h1.size() * 2); hipMalloc(&dh2, h2.size() * 2);
             hipMemcpy(dh1, h1.data(), h1.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dh2, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
             a.se_w1h = dh1; a.se_w2h = dh2;
+            // conv_zs_kernel: MFMA B-fragment pieces (net.hip)
+            const int NT1 = (Hd + 15) / 16, KS2 = (Hd + 31) / 32;
+            std::vector<_Float16> wf((size_t)(10 * NT1 + 20 * KS2) * 512, (_Float16)0.f);
+            for (int nt = 0; nt < NT1; ++nt) for (int ks = 0; ks < 10; ++ks) for (int l = 0; l < 64; ++l) for (int e = 0; e < 8; ++e) {
+                const int c = 32 * ks + 8 * (l >> 4) + e, j = 16 * nt + (l & 15);
+                if (j < Hd) wf[((size_t)(nt * 10 + ks) * 64 + l) * 8 + e] = (_Float16)w1[(size_t)c * Hd + j];
+            }
+            for (int nt = 0; nt < 20; ++nt) for (int ks = 0; ks < KS2; ++ks) for (int l = 0; l < 64; ++l) for (int e = 0; e < 8; ++e) {
+                const int j = 32 * ks + 8 * (l >> 4) + e, c = 16 * nt + (l & 15);
+                if (j < Hd) wf[((size_t)(10 * NT1 + nt * KS2 + ks) * 64 + l) * 8 + e] = (_Float16)w2[(size_t)j * C + c];
+            }
+            _Float16* dwf; hipMalloc(&dwf, wf.size() * 2); hipMemcpy(dwf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice);
+            a.se_wf = dwf;
         }
     }
 #endif
@@ -81,17 +98,44 @@ int main(int argc, char** argv) {
     unsigned long long* dst_; hipMalloc(&dst_, (size_t)(M / 256) * 16 * 8); hipMemset(dst_, 0, (size_t)(M / 256) * 16 * 8);
 #if defined(BENCH_SW)
     hipMemcpyToSymbol(HIP_SYMBOL(g_sw_stamp), &dst_, sizeof(dst_));
+#elif defined(BENCH_ZS)
+    hipMemcpyToSymbol(HIP_SYMBOL(g_zs_stamp), &dst_, sizeof(dst_));
 #elif defined(BENCH_P16)
     hipMemcpyToSymbol(HIP_SYMBOL(g_p16_stamp), &dst_, sizeof(dst_));
 #else
     hipMemcpyToSymbol(HIP_SYMBOL(g_pp_stamp), &dst_, sizeof(dst_));
 #endif
 #endif
+#if defined(SW_STAMP) && defined(BENCH_ZS) && defined(BENCH_TAIL)
+    unsigned long long* dztail_; hipMalloc(&dztail_, (size_t)(M / 256) * 8 * 8); hipMemset(dztail_, 0, (size_t)(M / 256) * 8 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_zs_tail_stamp), &dztail_, sizeof(dztail_));
+#endif
 #if defined(SW_STAMP) && defined(BENCH_P16) && defined(BENCH_TAIL)
     unsigned long long* dtail_; hipMalloc(&dtail_, (size_t)(M / 256) * 8 * 8); hipMemset(dtail_, 0, (size_t)(M / 256) * 8 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamp), &dtail_, sizeof(dtail_));
 #endif
     hipStream_t st; hipStreamCreate(&st);
+#ifdef BENCH_CMP   // conv_zs_kernel against conv_pp16_kernel on the same operands: outputs must agree bit for bit (stats / gate: closely)
+    {
+        const size_t nb = (size_t)M * C * 2;
+        std::vector<_Float16> o1((size_t)M * C), o2((size_t)M * C), p1((size_t)M * C), p2((size_t)M * C);
+        hipMemset(dout, 0, nb); if (a.y2) hipMemset(a.y2, 0, nb);
+        hipError_t e1 = launch_conv_pp16(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o1.data(), dout, nb, hipMemcpyDeviceToHost); if (a.y2) hipMemcpy(p1.data(), a.y2, nb, hipMemcpyDeviceToHost);
+        std::vector<float> s1, s2;
+        if (a.out_stats) { s1.resize((size_t)boards * C * 2); hipMemcpy(s1.data(), dstats, s1.size() * 4, hipMemcpyDeviceToHost); }
+        hipMemset(dout, 0, nb); if (a.y2) hipMemset(a.y2, 0, nb);
+        hipError_t e2 = launch_conv_zs(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o2.data(), dout, nb, hipMemcpyDeviceToHost); if (a.y2) hipMemcpy(p2.data(), a.y2, nb, hipMemcpyDeviceToHost);
+        if (a.out_stats) { s2.resize(s1.size()); hipMemcpy(s2.data(), dstats, s2.size() * 4, hipMemcpyDeviceToHost); }
+        size_t bad = 0, bad2 = 0; double md = 0, md2 = 0, ms = 0;
+        for (size_t i = 0; i < o1.size(); ++i) { const double d = fabs((double)o1[i] - (double)o2[i]); if (d != 0) ++bad; if (d > md) md = d; }
+        if (a.y2) for (size_t i = 0; i < p1.size(); ++i) { const double d = fabs((double)p1[i] - (double)p2[i]); if (d != 0) ++bad2; if (d > md2) md2 = d; }
+        for (size_t i = 0; i < s1.size(); ++i) { const double d = fabs((double)s1[i] - (double)s2[i]) / (1.0 + fabs((double)s1[i])); if (d > ms) ms = d; }
+        printf("compare conv_pp16 (%s) vs conv_zs (%s): out %zu differing elements (max |d| %.3g), y2 %zu (max %.3g), stats max rel %.3g; out[0..3] = %g %g %g %g\n",
+               hipGetErrorString(e1), hipGetErrorString(e2), bad, md, bad2, md2, ms, (double)o2[0], (double)o2[1], (double)o2[2], (double)o2[3]);
+    }
+#endif
     for (int i = 0; i < 3; ++i) launch_conv_pp(a, st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, st);
@@ -113,6 +157,17 @@ int main(int argc, char** argv) {
         std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
         printf("main loop per workgroup tile: median %.0f cycles (min %.0f max %.0f), in-kernel clock median %.0f MHz; ideal MFMA issue 115200 cycles -> %.1f %%\n",
                cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], 100.0 * 115200.0 / cyc[cyc.size() / 2]);
+    }
+#endif
+#if defined(SW_STAMP) && defined(BENCH_ZS) && defined(BENCH_TAIL)
+    {
+        const int nb = M / 256;
+        std::vector<unsigned long long> ht((size_t)nb * 8);
+        hipMemcpy(ht.data(), dztail_, ht.size() * 8, hipMemcpyDeviceToHost);
+        double d[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) for (int k = 0; k < 4; ++k) d[k] += (double)(ht[b * 8 + k + 1] - ht[b * 8 + k]);
+        printf("zs tail phases per workgroup (wave 0): SE gate %.2f us, stage + x loads %.2f us, y = x + t / store / stats %.2f us, y2 %.2f us\n",
+               d[0] / nb * 0.01, d[1] / nb * 0.01, d[2] / nb * 0.01, d[3] / nb * 0.01);
     }
 #endif
 #if defined(SW_STAMP) && defined(BENCH_P16) && defined(BENCH_TAIL)
