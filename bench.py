@@ -284,7 +284,7 @@ def main():
             "time_split_ms_per_pass": {"net": ms_net / args.gpus / max(1, args.steps * substeps),
                                        "tree": ms_tree / args.gpus / max(1, args.steps * substeps),
                                        "host": ms_host / args.gpus / max(1, args.steps * substeps)},
-            "roofline": {"bound": "mfma", "kernel": "conv_pp_kernel<*> (3x3 320->320 implicit GEMM, MFMA 32x32x16 f16)",
+            "roofline": {"bound": "mfma", "kernel": "conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped, MFMA 16x16x32 f16)",
                          "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
                          "launches": int(conv_launches), "avg_launch_us": (conv_ms * 1e3 / conv_launches) if conv_launches else None,

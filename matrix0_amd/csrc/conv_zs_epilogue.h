@@ -64,6 +64,11 @@ __device__ __forceinline__ void zs_tile_epilogue(float4v (&acc)[8][5], const Gem
     char* out = reinterpret_cast<char*>(a.out) + ((size_t)(m0 + wp * 128) * a.ldo + n0 + wn * 80) * 2;
     const int rows_valid = a.Mvalid - (m0 + wp * 128);
     if constexpr (EPI == 1) {
+        // pass 1: statistics -> per-column scale / shift.  Pass 2 goes board row by board row (M-tile mi = 8 squares of both
+        // boards = 8 complete image rows): normalise + activate + stage the row's 5 tiles, then store that row -- the global
+        // stores of row mi are in flight while the VALU works on row mi + 1 (staging everything first and flushing afterwards
+        // left the ~6 us of activation arithmetic and the 5 us store burst back to back).
+        float g[5], sh[5];
         static_for<0, 5>([&](auto ni_) __attribute__((always_inline)) {
             constexpr int ni = decltype(ni_)::value;
             const int col = colbase + ni * 16;
@@ -76,19 +81,37 @@ __device__ __forceinline__ void zs_tile_epilogue(float4v (&acc)[8][5], const Gem
             const float mean = s * (1.f / 1024.f);
             float var = ss * (1.f / 1024.f) - mean * mean;
             var = var > 0.f ? var : 0.f;
-            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
-            const float sh = a.gn_beta[col] - mean * g;
-            static_for<0, 8>([&](auto mi_) __attribute__((always_inline)) {
-                constexpr int mi = decltype(mi_)::value;
+            g[ni] = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
+            sh[ni] = a.gn_beta[col] - mean * g[ni];
+        });
+        const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
+        // row mi of the image = 8 squares x 20 chunks = 160 16-byte units: lanes 0..63 take units lane, 64 + lane and (lanes < 32)
+        // 128 + lane; unit u = (square u / 20, board-chunk u % 20)
+        int fsq[3], fc20[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int u = 64 * k + lane; fsq[k] = u / 20; fc20[k] = u - fsq[k] * 20; }
+        static_for<0, 8>([&](auto mi_) __attribute__((always_inline)) {
+            constexpr int mi = decltype(mi_)::value;
+            static_for<0, 5>([&](auto ni_) __attribute__((always_inline)) {
+                constexpr int ni = decltype(ni_)::value;
                 float v[4];
                 static_for<0, 4>([&](auto r_) __attribute__((always_inline)) {
                     constexpr int r = decltype(r_)::value;
-                    v[r] = act_fast<ACT>(acc[mi][ni][r] * g + sh);
+                    v[r] = act_fast<ACT>(acc[mi][ni][r] * g[ni] + sh[ni]);
                 });
                 zs_stage_tile<mi, ni>(v, wbase, lane);
             });
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < 2 || lane < 32) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(img + (mi * 160 + 64 * k + lane) * 16);
+                    const int bd = fc20[k] >= 10 ? 1 : 0;
+                    const int row = bd * 64 + mi * 8 + fsq[k];
+                    if (row < rows_valid)
+                        *reinterpret_cast<uint4*>(out + ((uint32_t)row * ldo2 + (uint32_t)(fc20[k] - 10 * bd) * 16u)) = v;
+                }
+            }
         });
-        zs_stage_flush(out, (uint32_t)a.ldo * 2u, rows_valid, img, lane);
     }
     if constexpr (EPI == 0) {
         const float oscale = a.out_scale;

@@ -12,5 +12,5 @@ sd = random_state_dict(cfg, seed=0, varied=True)
 be = M0Backend.from_state_dict(cfg, sd)
 fl = be.flops_per_position(False)
 for B in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096]:
-    ms = be.bench_forward(B, 3)
+    ms = be.bench_forward(B, int(os.environ.get("ITERS", "3")))
     print(json.dumps({"B": B, "ms": round(ms, 3), "pos_per_s": round(B / ms * 1e3), "TFLOPs": round(B * fl / ms / 1e9, 1)}), flush=True)
