@@ -190,7 +190,12 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
                         constexpr int ni = decltype(ni_)::value;
                         static_for<LO, HI>([&](auto mi_) __attribute__((always_inline)) {
                             constexpr int mi = decltype(mi_)::value;
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                            // operand order = accumulator layout (conv_zs_epilogue.h): weights as A for the plain / GroupNorm epilogues
+                            // (a lane gets 4 consecutive channels of a square), activations as A for the fused tail
+                            if constexpr (EPI == 3 || EPI == 5)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                            else
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
                         });
                         if constexpr (ni == 1) { ZS_FENCE(); issue_next(G_); ZS_FENCE(); }
                     });

@@ -4,7 +4,8 @@
 //   gate   = sigmoid(W2 act(W1 mean_squares(t) + b1) + b2)            squeeze-excite, resnet.py:59-68 (optional)
 //   y      = x + gate * t                                             the residual stream          -> a.out
 //   y2     = act(GroupNorm16(y; next block's bn1))                    the next conv1's operand     -> a.y2 (optional)
-// A wave = (board pair wp, channel quarter wn): 2 boards x 80 channels.
+// A wave = (board pair wp, channel quarter wn): 2 boards x 80 channels, accumulators in the activation-as-operand-A layout
+// (conv_zs_epilogue.h, zsa_* helpers): lane (c15, q) holds board q >> 1, square 8 mi + 4 (q & 1) + r, channel 16 ni + c15.
 //
 // Squeeze-excite on the matrix cores.  The two small FCs used to be scalar loops over LDS (5 barriers, ~7 us per tile, most
 // of it the 100 KB of fp32->fp16 weights arriving from L2).  Here:
@@ -170,7 +171,7 @@ __device__ __forceinline__ void zs_tail_epilogue(float4v (&acc)[8][5], const Gem
                 const float4v av = acc[decltype(mi_)::value][ni];
                 static_for<0, 4>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
             });
-            s = zs_sum_board(s); ss = zs_sum_board(ss);
+            s = zsa_sum_board(s); ss = zsa_sum_board(ss);
             const float mean = s * (1.f / 1024.f);
             float var = ss * (1.f / 1024.f) - mean * mean;
             var = var > 0.f ? var : 0.f;
@@ -183,7 +184,7 @@ __device__ __forceinline__ void zs_tail_epilogue(float4v (&acc)[8][5], const Gem
     // D: gate * t -> the wave's fp16 image; the loads of x are issued between the tile columns, into the registers
     // the staged accumulators free (x is 2-3 us away and nothing else runs on this CU)
     char* img = smem + wave * 20480;
-    char* wbase = zs_stage_base(img, lane);
+    char* wbase = zsa_stage_base(img, lane);
     const uint32_t ldo2 = (uint32_t)a.ldo * 2u;
     const size_t tile_off = ((size_t)(m0 + wp * 128) * a.ldo + wn * 80) * 2;      // wave-uniform
     const char* xin = reinterpret_cast<const char*>(a.res) + tile_off;
@@ -202,7 +203,7 @@ __device__ __forceinline__ void zs_tail_epilogue(float4v (&acc)[8][5], const Gem
                 if constexpr (PRE) v[r] = act_fast<ACT>(acc[mi][ni][r] * gv[ni] + pv[ni]);
                 else v[r] = acc[mi][ni][r] * gv[ni];
             });
-            zs_stage_tile<mi, ni>(v, wbase, lane);
+            zsa_stage_tile<mi, ni>(v, wbase, lane);
         });
         __builtin_amdgcn_sched_barrier(0);
         // the 22 loads of x spread over the 5 channel tiles (5 after each of the first two, 4 after the others)
