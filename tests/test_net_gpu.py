@@ -133,6 +133,33 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
             _check(f"tail_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
 
 
+def test_conv_kernel_variants_agree(monkeypatch):
+    """The three 3x3 conv kernels compute the same convolution: conv_zs_kernel (default: the MFMA tiles that only multiply zero
+    padding are not issued, squeeze-excite FCs on the matrix cores), conv_pp16_kernel (M0_CONV_ZS=0) and conv_pp_kernel
+    (M0_CONV_ZS=0 M0_CONV_MFMA32=1 is read once per process, so only the first two are switched here).  Variants: silu + SE
+    (80 hidden units), relu + SE, a small SE ratio (hidden = 8: one FC1 tile, one FC2 k-step), and a ragged batch."""
+    from matrix0_amd.backend import M0Backend
+    for extra in ({}, {"activation": "relu"}, {"se_ratio": 0.025}):
+        cfg = dict(_r24_cfg(), blocks=3, **extra)
+        sd = net_ref.random_state_dict(cfg, seed=21)
+        be = M0Backend.from_state_dict(cfg, sd)
+        g = torch.Generator().manual_seed(31)
+        B = 41
+        x = torch.zeros(B, 19, 8, 8)
+        x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+        x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+        x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+        monkeypatch.setenv("M0_CONV_ZS", "0")
+        p16, v16 = be.infer_np(x.numpy())
+        monkeypatch.setenv("M0_CONV_ZS", "1")
+        pzs, vzs = be.infer_np(x.numpy())
+        assert np.abs(pzs - p16).max() <= 2e-3, extra
+        assert np.abs(vzs - v16).max() <= 2e-3, extra
+        p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
+        for tag, p, v in (("pp16", p16, v16), ("zs", pzs, vzs)):
+            _check(f"conv_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
+
+
 def test_fused_attention_block_matches_split_kernels(monkeypatch):
     """The whole attention block in one kernel (attn_block.hip: qkv GEMM, scores/softmax/PV, proj GEMM, residual,
     LayerNorm, the next block's GroupNorm + activation) vs qkv + attn_core + proj + ew_board as four kernels, on a ragged
