@@ -261,12 +261,10 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     } else if (taps == 1) {
         if (big) return a.w_pp ? hipErrorInvalidValue : launch_conv_big(a, 1, st);
         // Head convs over the whole trunk (M = 64 x boards, N = 64 / 128): a workgroup per 32 output channels re-reads its 256
-        // trunk rows once per N block (168 MB x 2..4 at 4096 boards); with the whole N in one workgroup the trunk is read once.
+        // trunk rows once per N block (168 MB x 2..4 at 4096 boards); 64 channels per workgroup halve that.
         // Same arithmetic per output element (bit-identical).  The FCs (M = boards) keep the narrow tile: they need the workgroups.
-        if (a.Mrows / 256 >= 256) {
-            if (a.Npad == 128) return launch_conv_gemm_t<1, 1, 4, 32>(a, st);
-            if (a.Npad == 64) return launch_conv_gemm_t<1, 1, 2, 32>(a, st);
-        }
+        // (64 channels per workgroup; 128 -- the whole value-head conv in one workgroup -- measured slower: 200 registers)
+        if (a.Mrows / 256 >= 256 && a.Npad % 64 == 0) return launch_conv_gemm_t<1, 1, 2, 32>(a, st);
         return launch_conv_gemm_t<1, 1, 1, 32>(a, st);
     }
     return hipErrorInvalidValue;
