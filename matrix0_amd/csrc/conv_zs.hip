@@ -60,11 +60,6 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     const int q = lane >> 4;
 
     reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);          // 512 x 16 B = the whole zero region
-#ifdef ZS_STAGGER     // experiment: the workgroups of the odd XCDs start ZS_STAGGER x 4 us late (first round only)
-    if ((EPI == 3) && (blockIdx.x & 1) && blockIdx.x < 256) {
-        for (int i = 0; i < ZS_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     const char* in_bytes = reinterpret_cast<const char*>(a.in);
     const char* w_blk = reinterpret_cast<const char*>(a.w) + (size_t)blockIdx.y * (2 * ZS_WH_BYTES) + lane * 16;
