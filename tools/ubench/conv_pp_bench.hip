@@ -4,7 +4,7 @@
 // With -DPP_TRACE it prints, for waves 0 and 4 of one workgroup and 4 consecutive K-tiles, the cycle stamps
 // L-start / L-end(before barrier) / C-start(after barrier) / C-end(MFMAs issued) of each phase.
 #include "../../matrix0_amd/csrc/conv_pp.hip"
-#include "../../matrix0_amd/csrc/conv_sw.hip"
+#include "conv_sw.hip"
 #include "../../matrix0_amd/csrc/conv_pp16.hip"
 #include "../../matrix0_amd/csrc/conv_zs.hip"
 #ifdef BENCH_ZS

@@ -14,8 +14,8 @@
 //        B_y only the two youngest groups (y+2, y+3) may still be in flight: vmcnt(12)
 //   WAR  the pieces of y+4 overwrite the slot of y and are issued after B_y, before which every wave has retired its reads
 //        of (y,0) and (y,1) (lgkmcnt(0))
-#include "kernel_common.h"
-#include "conv_epilogue.h"
+#include "../../matrix0_amd/csrc/kernel_common.h"
+#include "../../matrix0_amd/csrc/conv_epilogue.h"
 
 __device__ __forceinline__ void sw_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
