@@ -9,8 +9,10 @@ ResNet-24 "53M" (R24-320), 1/2/4/8 MI355X).
 A "step" is one searched ply for every resident game: ceil(sims / leaves) passes of the hot path, each pass =
 for every resident game tree select up to `leaves` leaves (PUCT + virtual loss), encode them into the network input,
 run the R24-320 forward on the whole batch (games x leaves positions), expand + back up; searches that complete
-(800 simulations per move, +-5 % playout cap) play their move and start the next search.  `--steps 20` therefore
-searches and plays ~20 plies in each of the 256 games.  Inputs are resident in HBM; weights are random-init R24-320
+(800 simulations per move, +-5 % playout cap) play their move and start the next search.  `leaves` defaults to the
+reference's own leaf batch, mcts.inference_batch_size = 96 (config.yaml:157): a step is then 9 passes of up to 24 576
+positions (a search needs 8.33 of them, so `--steps 20` searches and plays ~21 plies in each of the 256 games; the plies are
+counted, not assumed).  Inputs are resident in HBM; weights are random-init R24-320
 (synthetic: no checkpoint, no dataset).  One process per GPU; games shard across GPUs with no data-path collective
 (RCCL is used only to broadcast the weights from rank 0), so scaling is "weak".
 
@@ -152,7 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one searched ply per resident game")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU (BASELINE configs[1])")
-    ap.add_argument("--leaves", type=int, default=16, help="leaves per tree and step (<= mcts.inference_batch_size)")
+    ap.add_argument("--leaves", type=int, default=96,
+                    help="leaves per tree and pass = mcts.inference_batch_size of the reference's config.yaml (96)")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--ssl", action="store_true", help="run the 5 SSL heads in every evaluation (configs[3])")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -264,8 +267,10 @@ def main():
                              "avg_launch_us": ((conv_ms - tail_ms) * 1e3 / plain_n) if plain_n else None,
                              "achieved": (flop_per_launch / ((conv_ms - tail_ms) * 1e-3 / plain_n) / 1e12) if plain_n else None}}
         traffic = None
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))["hbm_bytes_per_launch"]
+        try:        # PMC bytes per launch at the profiled batch, scaled to this run's boards per launch (HBM traffic is per board)
+            ct = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
+            boards_per_launch = evals / max(1.0, args.gpus * args.steps * substeps)
+            traffic = int(ct["hbm_bytes_per_launch"] * boards_per_launch / float(ct.get("boards_per_launch", 4096)))
         except Exception:
             pass
         out = {

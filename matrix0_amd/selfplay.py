@@ -100,7 +100,7 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     # SSL targets are generated whenever the model has SSL enabled (selfplay/internal.py:312-318)
     ssl_tasks = list(model_cfg.get("ssl_tasks", [])) if model_cfg.get("self_supervised", False) else []
     concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
-    eng_kw = dict(seed=base_seed, leaves_per_step=eng_cfg.get("leaves_per_step", 16),
+    eng_kw = dict(seed=base_seed, leaves_per_step=eng_cfg.get("leaves_per_step"),          # None: mcts.inference_batch_size, as the reference
                   virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
                   ssl_targets=bool(ssl_tasks), arena_nodes=int(eng_cfg.get("arena_nodes", 0) or 0))
     # engine.streams > 1: that many independent engines (own network instance and HIP stream each) share the games and

@@ -8,6 +8,7 @@ set -o pipefail
 TAG=${1:-r02}
 OUT=gpurun_out
 K='conv_zs_kernel'
+B=${2:-24576}        # boards per forward in the bench: 256 games x 96 leaves
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/$TAG.bench.json 2> $OUT/$TAG.bench.err || exit 1
@@ -16,13 +17,13 @@ python bench.py --ssl --no-cpu-baseline > $OUT/$TAG.bench_ssl.json 2> $OUT/$TAG.
 echo "[profile] bench --ssl done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/$TAG.bench_prof.json 2> $OUT/$TAG.stats.err || exit 1
 echo "[profile] kernel stats done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.netstats -- python3 tools/bench_net.py 4096 > $OUT/$TAG.netstats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.netstats -- python3 tools/bench_net.py $B > $OUT/$TAG.netstats.log 2>&1 || exit 1
 echo "[profile] forward stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_$C -- python3 tools/bench_net.py 4096 > $OUT/$TAG.pmc_$C.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_$C -- python3 tools/bench_net.py $B > $OUT/$TAG.pmc_$C.log 2>&1 || exit 1
   echo "[profile] pmc $C done"
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_sq -- python3 tools/bench_net.py 4096 > $OUT/$TAG.pmc_sq.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_sq -- python3 tools/bench_net.py $B > $OUT/$TAG.pmc_sq.log 2>&1 || exit 1
 echo "[profile] pmc sq done"
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_LDS --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_lds -- python3 tools/bench_net.py 4096 > $OUT/$TAG.pmc_lds.log 2>&1 || echo "[profile] pmc lds failed (optional)"
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_LDS --kernel-include-regex "$K" --output-format csv -d $OUT/$TAG.pmc_lds -- python3 tools/bench_net.py $B > $OUT/$TAG.pmc_lds.log 2>&1 || echo "[profile] pmc lds failed (optional)"
 echo "[profile] all done"

@@ -5,13 +5,14 @@
 
 profiles/<tag>_bench.json, _bench_ssl.json          the bench lines
 profiles/<tag>_bench_kernel_stats.csv               rocprofv3 --stats of `bench.py --steps 10 --warmup 3`
-profiles/<tag>_net_forward_B4096_kernel_stats.csv   rocprofv3 --stats of tools/bench_net.py 4096
+profiles/<tag>_net_forward_B<boards>_kernel_stats.csv  rocprofv3 --stats of tools/bench_net.py <boards>
 profiles/<tag>_conv_pmc_<counter>.csv               per-dispatch counters of the dominant kernel (trimmed columns)
 profiles/conv_traffic.json                          hbm_bytes_per_launch etc. (read by bench.py for roofline.traffic)
 """
 import csv, glob, json, os, shutil, statistics, sys
 
 tag = sys.argv[1]
+boards = int(sys.argv[2]) if len(sys.argv) > 2 else 24576        # boards per forward of the PMC passes (tools/profile_round.sh)
 G = "gpurun_out"
 P = "profiles"
 
@@ -33,7 +34,7 @@ for name in ("bench", "bench_ssl"):
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, f"{tag}_{name}.json"))
 copy(f"{G}/{tag}.stats/**/*_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv")
-copy(f"{G}/{tag}.netstats/**/*_kernel_stats.csv", f"{tag}_net_forward_B4096_kernel_stats.csv")
+copy(f"{G}/{tag}.netstats/**/*_kernel_stats.csv", f"{tag}_net_forward_B{boards}_kernel_stats.csv")
 
 per_counter = {}
 for d in sorted(glob.glob(f"{G}/{tag}.pmc_*")):
@@ -56,9 +57,10 @@ for d in sorted(glob.glob(f"{G}/{tag}.pmc_*")):
         per_counter.setdefault(r["Counter_Name"], {}).setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
 
 if "FETCH_SIZE" in per_counter and "WRITE_SIZE" in per_counter:
-    out = {"kernel": "conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped), B = 4096 boards per launch",
+    out = {"kernel": f"conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped), B = {boards} boards per launch",
+           "boards_per_launch": boards,
            "collected": f"tools/profile_round.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) "
-                        "--kernel-include-regex conv_zs_kernel -- python3 tools/bench_net.py 4096; medians per kernel variant, "
+                        f"--kernel-include-regex conv_zs_kernel -- python3 tools/bench_net.py {boards}; medians per kernel variant, "
                         "launch-weighted mean",
            "correction": "gfx950: FETCH_SIZE counts 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): fetch bytes = "
                          "2 x FETCH_SIZE KB; WRITE_SIZE KB taken as is",
@@ -72,9 +74,9 @@ if "FETCH_SIZE" in per_counter and "WRITE_SIZE" in per_counter:
         tot_b += (fmb + wmb) * 1e6 * len(fv)
         tot_n += len(fv)
     out["hbm_bytes_per_launch"] = int(tot_b / max(tot_n, 1))
-    out["algorithmic_bytes_per_launch"] = 337400000
-    out["algorithmic_note"] = ("plain/conv1: input 4096*64*320*2 B + output the same + 1.84 MB weights = 337.4 MB; conv2 with tail: "
-                               "+ x read + second output = 673 MB")
+    out["algorithmic_bytes_per_launch"] = int(boards * 64 * 320 * 2 * 2 + 1843200)
+    out["algorithmic_note"] = (f"plain/conv1: input {boards}*64*320*2 B + output the same + 1.84 MB weights; conv2 with tail: "
+                               "+ x read + second output (twice the activation bytes)")
     sq = {}
     for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
               "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_LDS"):
