@@ -149,6 +149,11 @@ def cpu_baseline(seconds: float, plies_per_game: float, threads: int = 4):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result.  Native libraries write there too (RCCL prints a version banner at the
+    # first communicator), so file descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one searched ply per resident game")
@@ -298,7 +303,8 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     e.close()
     if distributed:
         dist.barrier()
