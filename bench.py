@@ -10,9 +10,10 @@ A "step" is one searched ply for every resident game: ceil(sims / leaves) passes
 for every resident game tree select up to `leaves` leaves (PUCT + virtual loss), encode them into the network input,
 run the R24-320 forward on the whole batch (games x leaves positions), expand + back up; searches that complete
 (800 simulations per move, +-5 % playout cap) play their move and start the next search.  `leaves` defaults to the
-reference's own leaf batch, mcts.inference_batch_size = 96 (config.yaml:157): a step is then 9 passes of up to 24 576
-positions (a search needs 8.33 of them, so `--steps 20` searches and plays ~21 plies in each of the 256 games; the plies are
-counted, not assumed).  Inputs are resident in HBM; weights are random-init R24-320
+reference's own leaf batch, mcts.inference_batch_size = 96 (config.yaml:157): a ply is then 9 passes of up to 24 576
+positions.  The timed region is EXACTLY `--steps` searched plies per resident game: passes are issued until the engine's
+ply counter has advanced by steps x games (the games search in step, so the region starts and ends right after a round of
+moves and the result does not depend on the window length).  Inputs are resident in HBM; weights are random-init R24-320
 (synthetic: no checkpoint, no dataset).  One process per GPU; games shard across GPUs with no data-path collective
 (RCCL is used only to broadcast the weights from rank 0), so scaling is "weak".
 
@@ -231,15 +232,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    substeps = -(-args.sims // args.leaves)          # passes of the hot path per searched ply
+    substeps = -(-args.sims // args.leaves)          # passes of the hot path per searched ply (all games in step)
+
+    def run_plies(n):
+        """Passes of the hot path until `n` more plies per resident game have been searched and played (counted by the
+        engine).  The games search in step, so the region starts and ends right after a round of moves: the measured
+        plies / time does not depend on where a fixed number of passes would have cut the searches."""
+        target = e.stats()["plies"] + n * args.games
+        passes = 0
+        while e.stats()["plies"] < target and passes < 4 * n * substeps:
+            e.step(1)
+            passes += 1
+        return passes
+
     if args.warmup > 0:
-        e.step(args.warmup * substeps)
+        run_plies(args.warmup)
     be.profile_enable(True)
     be.profile_get(reset=True)
     s0 = e.stats()
     sync()
     t0 = time.perf_counter()
-    e.step(args.steps * substeps)
+    passes_timed = run_plies(args.steps)
     sync()
     dt = time.perf_counter() - t0
     s1 = e.stats()
@@ -248,9 +261,10 @@ def main():
 
     d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total")}
     counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
-                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"]], dtype=np.float64)
+                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed], dtype=np.float64)
     dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
-    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims = [float(x) for x in tot]
+    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all = [float(x) for x in tot]
+    passes = max(1.0, passes_all / args.gpus)           # passes per rank in the timed region
 
     if rank == 0:
         ppg, basis_src = game_length_basis()
@@ -274,7 +288,7 @@ def main():
         traffic = None
         try:        # PMC bytes per launch at the profiled batch, scaled to this run's boards per launch (HBM traffic is per board)
             ct = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
-            boards_per_launch = evals / max(1.0, args.gpus * args.steps * substeps)
+            boards_per_launch = evals / max(1.0, args.gpus * passes)
             traffic = int(ct["hbm_bytes_per_launch"] * boards_per_launch / float(ct.get("boards_per_launch", 4096)))
         except Exception:
             pass
@@ -290,10 +304,9 @@ def main():
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
-            "passes_per_step": substeps, "ms_per_pass": dt_max * 1e3 / max(1, args.steps * substeps),
-            "time_split_ms_per_pass": {"net": ms_net / args.gpus / max(1, args.steps * substeps),
-                                       "tree": ms_tree / args.gpus / max(1, args.steps * substeps),
-                                       "host": ms_host / args.gpus / max(1, args.steps * substeps)},
+            "passes_per_step": passes / max(1, args.steps), "ms_per_pass": dt_max * 1e3 / passes,
+            "time_split_ms_per_pass": {"net": ms_net / args.gpus / passes, "tree": ms_tree / args.gpus / passes,
+                                       "host": ms_host / args.gpus / passes},
             "roofline": {"bound": "mfma", "kernel": "conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped, MFMA 16x16x32 f16)",
                          "achieved": achieved / 1e12, "peak": PEAK_FP16_DENSE / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_DENSE, "traffic": traffic,
