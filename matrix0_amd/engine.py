@@ -312,7 +312,7 @@ class SelfplayPool:
     concurrently, one host thread each (the C calls release the GIL).  Games never interact, so nothing else changes --
     a game's record depends only on (seed, game index), whichever engine plays it -- but the tree kernels, launch
     boundaries and epilogue HBM bursts of one share now overlap the network kernels of the other: +3..4 % evaluations/s
-    at 2 x 128 games against 1 x 256 (tools/try_two_engines.py; 4 x 64 gives nothing more).  Costs one more copy of the
+    at 2 x 128 games against 1 x 256 (bench.py --streams 2; 4 x 64 gives nothing more).  Costs one more copy of the
     weights in HBM.  Per-launch kernel timings taken in this mode include the other stream's kernels."""
 
     def __init__(self, backend_factory, cfg_dict: dict, *, streams: int, concurrent_games: int, total_games: int = 0,
