@@ -227,10 +227,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
                     constexpr int ni = decltype(ni_)::value;
                     static_for<0, MT>([&](auto mi_) __attribute__((always_inline)) {
                         constexpr int mi = decltype(mi_)::value;
-#ifdef P16_SKIPTEST      // timing experiment only (wrong results): drop one of the 4 M-tiles for the taps of the first row(s)
-                        if constexpr (mi == 0) { if (tap >= P16_SKIPTEST) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0); }
-                        else
-#endif
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
                     });
                     if constexpr (ni == 2) { P16_FENCE(); issue_next(G_); P16_FENCE(); }
