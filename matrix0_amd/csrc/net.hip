@@ -405,6 +405,7 @@ int Net::finalize(std::string& err) {
         }
     }
     sd_.clear();
+    (void)hipDeviceSynchronize();       // uploads and clears (NULL stream) have landed before any non-blocking stream reads them
     finalized_ = true;
     return M0_OK;
 }
@@ -469,6 +470,9 @@ int Net::ensure_workspace(int B, std::string& err) {
         wsB_ = wsM_ = 0;
         return M0_ERR_HIP;
     }
+    // dalloc clears with hipMemset on the NULL stream; the forward runs on a non-blocking stream that does not wait for it -- without
+    // this the clears of a regrown workspace (GBs at self-play batch sizes) race with the first kernels that write it
+    if (hipDeviceSynchronize() != hipSuccess) { err = "workspace clear failed"; wsB_ = wsM_ = 0; return M0_ERR_HIP; }
     wsB_ = Bp; wsM_ = Mfc;
     return M0_OK;
 }
@@ -496,11 +500,13 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
         (void)hipEventRecord(pev_[pev_used_], st);
     }
     hipError_t rc;
-    // a long-K 1x1 GEMM over few rows (value_fc1: K = 8192, 32 tiles on 256 CUs): split K eight ways into fp32 partial
-    // tiles, then a fixed-order reduction with the bias and the activation
-    const int tiles = (Mrows / 256) * (g.N / 320);
-    const bool splitk = g.taps == 1 && conv_gemm_tile_n(g.Cin, g.N) == 320 && g.Cin >= 4096 && (g.Cin >> 6) % 8 == 0 &&
-                        tiles <= 64 && !out_norm && !mul && !out_stats && !out_f32 && out_scale == 1.f && SPK_ != nullptr &&
+    // a long-K 1x1 GEMM (value_fc1: K = 8192; 32 tiles on 256 CUs at 4096 boards): split K eight ways into fp32 partial
+    // tiles, then a fixed-order reduction with the bias and the activation.  Taken at EVERY batch size: the summation order of a
+    // board's value must not depend on how many other boards share the launch (tests/test_net_gpu.py: bitwise batch invariance up
+    // to the 24 832 boards of a self-play pass); at large batches the partial tiles cost ~0.1 % of the forward.
+    const char* skenv = getenv("M0_SPLITK");           // =0: never split (A/B runs)
+    const bool splitk = !(skenv && skenv[0] == '0') && g.taps == 1 && conv_gemm_tile_n(g.Cin, g.N) == 320 && g.Cin >= 4096 &&
+                        (g.Cin >> 6) % 8 == 0 && !out_norm && !mul && !out_stats && !out_f32 && out_scale == 1.f && SPK_ != nullptr &&
                         (size_t)g.N <= (size_t)ceil_to(2 * C_, 32) && Mrows <= wsM_;
     if (splitk) {
         a.out = SPK_; a.bias = nullptr; a.epi_act = ACT_NONE; a.out_f32 = 1; a.ksplit = 8;

@@ -596,7 +596,9 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
         if (sp->net->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
         if (sp->net_b && sp->net_b->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
     }
-    (void)hipStreamSynchronize(sp->stream);
+    // the allocations above were cleared with hipMemset on the NULL stream, which the engine's non-blocking stream does not wait
+    // for: everything must have landed before the first kernel touches the arenas
+    (void)hipDeviceSynchronize();
     return sp;
 }
 

@@ -329,6 +329,49 @@ def test_full_size_batch_invariance_and_determinism():
     assert start == B
 
 
+def test_bench_size_forward_is_batch_invariant():
+    """The forward of a self-play pass at the bench configuration takes 256 games x 96 leaves (+ 256 re-evaluated roots): 24 832
+    boards in one launch sequence, 24 rounds of workgroups per CU in the conv kernels.  Boards 0..63 and the last 61 boards of
+    that batch must come out bit for bit as they do in a 64- / 61-board call (logits of 4672 floats per board: only these slices
+    are copied back and compared)."""
+    from matrix0_amd.backend import M0Backend
+    cfg = _r24_cfg()
+    be = M0Backend.from_state_dict(cfg, net_ref.random_state_dict(cfg, seed=0))
+    rng = np.random.default_rng(17)
+    B = 24832
+    x = np.zeros((B, 19, 8, 8), np.float32)
+    x[:, :12] = (rng.random((B, 12, 8, 8)) < 0.08).astype(np.float32)
+    x[:, 12:17] = (rng.random((B, 5, 1, 1)) < 0.5).astype(np.float32)
+    x[:, 17:] = rng.random((B, 2, 1, 1)).astype(np.float32)
+    p_all, v_all = be.infer_np(x)
+    assert np.isfinite(p_all).all() and np.isfinite(v_all).all() and np.abs(v_all).max() <= 1.0
+    p0, v0 = be.infer_np(x[:64])
+    assert np.array_equal(p0, p_all[:64]) and np.array_equal(v0, v_all[:64])
+    p1, v1 = be.infer_np(x[B - 61:])
+    assert np.array_equal(p1, p_all[B - 61:]) and np.array_equal(v1, v_all[B - 61:])
+
+
+def test_workspace_regrowth_keeps_results():
+    """A backend that is called with growing batches re-allocates (and clears) its workspace: the clears run on the NULL stream,
+    the forward on a non-blocking one, so the re-allocation must be complete before the first kernel writes the new buffers
+    (a missing synchronisation there once gave garbage, differing from run to run, for the first call after every regrowth)."""
+    from matrix0_amd.backend import M0Backend
+    cfg = dict(_r24_cfg(), blocks=6)
+    be = M0Backend.from_state_dict(cfg, net_ref.random_state_dict(cfg, seed=2))
+    rng = np.random.default_rng(23)
+    B = 12288
+    x = np.zeros((B, 19, 8, 8), np.float32)
+    x[:, :12] = (rng.random((B, 12, 8, 8)) < 0.08).astype(np.float32)
+    x[:, 12:17] = (rng.random((B, 5, 1, 1)) < 0.5).astype(np.float32)
+    x[:, 17:] = rng.random((B, 2, 1, 1)).astype(np.float32)
+    p0, v0 = be.infer_np(x[:64])
+    for n in (700, 5000, 9000, B):                       # every call regrows the workspace
+        p, v = be.infer_np(x[:n])
+        assert np.array_equal(p[:64], p0) and np.array_equal(v[:64], v0), n
+        p2, v2 = be.infer_np(x[:n])
+        assert np.array_equal(p, p2) and np.array_equal(v, v2), n
+
+
 def test_infer_np_rejects_bad_shape_and_nan():
     from matrix0_amd.backend import M0Backend
     cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
