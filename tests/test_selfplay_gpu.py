@@ -190,9 +190,11 @@ def test_worker_direct_replay_shards(tmp_path):
     assert rows[0] == total and rows[1] == len(shards)
 
 
-def test_full_size_configuration_properties():
-    """BASELINE configs[1] at full size -- 256 concurrent games, 800 simulations per move, R24-320, 16 leaves per tree and
-    step -- cut to 2 searched plies per game: the invariants that do not depend on size.  Every searched ply spent
+@pytest.mark.parametrize("leaves", [96, 16])
+def test_full_size_configuration_properties(leaves):
+    """BASELINE configs[1] at full size -- 256 concurrent games, 800 simulations per move, R24-320, 96 leaves per tree and
+    pass (the reference's mcts.inference_batch_size, bench.py's default: 24 576 positions per forward) and 16 -- cut to 2
+    searched plies per game: the invariants that do not depend on size.  Every searched ply spent
     exactly its simulation budget (800, or the reduced playout cap), pi is the normalised visit distribution over
     legal moves only, every played move is legal and was visited, planes/masks equal the oracle's on replay."""
     import bench
@@ -201,7 +203,7 @@ def test_full_size_configuration_properties():
     cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.SELFPLAY_CFG.items()}
     cfgd["selfplay"] = dict(cfgd["selfplay"], max_game_len=2)
     be = M0Backend.from_state_dict(bench.R24_320, net_ref.random_state_dict(bench.R24_320, seed=0))
-    cfg = eng.selfplay_cfg_from_dict(cfgd, concurrent_games=256, total_games=256, leaves_per_step=16,
+    cfg = eng.selfplay_cfg_from_dict(cfgd, concurrent_games=256, total_games=256, leaves_per_step=leaves,
                                      virtual_loss_active=True, record_games=True)
     e = eng.SelfplayEngine(be, cfg)
     games = []
@@ -238,6 +240,38 @@ def test_full_size_configuration_properties():
                 assert np.array_equal(g["legal_mask"][t].astype(bool), ch.get_legal_actions(b))
                 assert g["pi"][t][ch.move_to_index(b, m)] > 0
             b.push(m)
+
+
+def test_a_game_does_not_depend_on_the_games_it_shares_the_gpu_with():
+    """The random streams are keyed by (seed, game index) and the network forward is bitwise batch-invariant, so game k is the
+    same game whether it is searched next to 255 others (24 576 positions per forward) or next to 3: moves, visit
+    distributions and outcomes of games 0..3 agree bit for bit between the two runs (what makes results independent of how
+    the games are sharded over workers and GPUs)."""
+    import bench
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.SELFPLAY_CFG.items()}
+    cfgd["selfplay"] = dict(cfgd["selfplay"], max_game_len=2)
+    be = M0Backend.from_state_dict(bench.R24_320, net_ref.random_state_dict(bench.R24_320, seed=0))
+    runs = []
+    for G in (256, 4):
+        cfg = eng.selfplay_cfg_from_dict(cfgd, concurrent_games=G, total_games=G, leaves_per_step=96,
+                                         virtual_loss_active=True, record_games=True)
+        e = eng.SelfplayEngine(be, cfg)
+        games = {}
+        for _ in range(200):
+            e.step(6)
+            while (r := e.poll()) is not None:
+                games[r["game_index"]] = r
+            if not e.running():
+                break
+        assert len(games) == G
+        runs.append(games)
+        e.close()
+    for k in range(4):
+        a, b = runs[0][k], runs[1][k]
+        assert a["played"] == b["played"], k
+        assert np.array_equal(a["pi"], b["pi"]) and np.array_equal(a["z"], b["z"]) and np.array_equal(a["s"], b["s"]), k
 
 
 def test_full_size_selfplay_is_reproducible():
