@@ -331,8 +331,8 @@ def test_full_size_batch_invariance_and_determinism():
 
 def test_bench_size_forward_is_batch_invariant():
     """The forward of a self-play pass at the bench configuration takes 256 games x 96 leaves (+ 256 re-evaluated roots): 24 832
-    boards in one launch sequence, 24 rounds of workgroups per CU in the conv kernels.  Boards 0..63 and the last 61 boards of
-    that batch must come out bit for bit as they do in a 64- / 61-board call (logits of 4672 floats per board: only these slices
+    boards in one launch sequence, 24 rounds of workgroups per CU in the conv kernels.  Boards 0..63, the last 61 boards and five 70-board
+    slices of that batch must come out bit for bit as they do in a small call (logits of 4672 floats per board: only these slices
     are copied back and compared)."""
     from matrix0_amd.backend import M0Backend
     cfg = _r24_cfg()
@@ -349,6 +349,9 @@ def test_bench_size_forward_is_batch_invariant():
     assert np.array_equal(p0, p_all[:64]) and np.array_equal(v0, v_all[:64])
     p1, v1 = be.infer_np(x[B - 61:])
     assert np.array_equal(p1, p_all[B - 61:]) and np.array_equal(v1, v_all[B - 61:])
+    for start in (4093, 8190, 12289, 16411, 20477):          # slices across tile / launch-round boundaries
+        p, v = be.infer_np(x[start:start + 70])
+        assert np.array_equal(p, p_all[start:start + 70]) and np.array_equal(v, v_all[start:start + 70]), start
 
 
 def test_workspace_regrowth_keeps_results():
