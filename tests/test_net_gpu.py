@@ -352,6 +352,13 @@ def test_bench_size_forward_is_batch_invariant():
     for start in (4093, 8190, 12289, 16411, 20477):          # slices across tile / launch-round boundaries
         p, v = be.infer_np(x[start:start + 70])
         assert np.array_equal(p, p_all[start:start + 70]) and np.array_equal(v, v_all[start:start + 70]), start
+    # the 5 SSL heads in the same forward (BASELINE configs[3] at this batch size): same property
+    ps, vs, ssl_all = be.infer_np_ssl(x)
+    assert np.array_equal(ps, p_all) and np.array_equal(vs, v_all)
+    for start in (0, 12289, B - 70):
+        _, _, ssl = be.infer_np_ssl(x[start:start + 70])
+        for task, t in ssl.items():
+            assert np.array_equal(t, ssl_all[task][start:start + 70]), (task, start)
 
 
 def test_workspace_regrowth_keeps_results():
