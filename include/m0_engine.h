@@ -115,6 +115,10 @@ int m0_net_profile_get_tail(m0_net* net, double* tail_ms, int64_t* tail_launches
  *   moves u16 [n,256] (from | to<<6 | promo<<12, promo 1..4 = N,B,R,Q) in legal_moves order; idx i32 [n,256]. */
 int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes, uint8_t* mask, int32_t* nlegal,
                    uint16_t* moves, int32_t* idx);
+/* The network's own input image of the same positions: fp16 bits, NHWC [n][64 squares][32 channels] (19 used, square
+ * n = row*8+col of the reference tensor), written by the device function the search's select kernel calls for every
+ * leaf (csrc/tree.hip encode_nhwc) -- i.e. encode_board (encoding.py:11-46) as the timed path evaluates it. */
+int m0_encode_fens_nhwc(int hip_device, const char* const* fens, int n, uint16_t* nhwc);
 /* MoveEncoder.decode_move (encoding.py:174-229): policy index -> UCI (auto-queen, legal fallbacks); "0000" = null move.
  * uci_out: at least 6 bytes. */
 int m0_decode_move_fen(int hip_device, const char* fen, int action_idx, char* uci_out);
@@ -216,8 +220,12 @@ int m0_selfplay_set_openings(m0_selfplay* sp, const char* const* fens, int n);
  * NULL): ext_select runs select for all resident games and returns the leaf planes f32 [rows,19,8,8]; ext_expand takes
  * logits f32 [rows,4672] and values f32 [rows], expands / backs up, and does the host part of the step (moves, game
  * ends, restarts) exactly as m0_selfplay_step does.  Parity tests play whole games against golden files this way. */
+/* max_rows must be >= concurrent_games * (inference_batch_size + 1) (checked before anything runs). */
 int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_rows);
 int m0_selfplay_ext_expand(m0_selfplay* sp, const float* logits, const float* values, int rows);
+/* The network batch the last select (m0_selfplay_ext_select / m0_search_select) wrote on the device: fp16 bits
+ * [rows][64][32], row order = the planes rows of that call.  This is what m0_selfplay_step feeds the network. */
+int m0_selfplay_last_batch_nhwc(m0_selfplay* sp, uint16_t* nhwc, int max_rows, int* rows);
 
 /* Evaluation match between two networks (azchess/arena.py:59-126 _arena_run_one_game, :305 play_match): game i is played
  * with net_a as White when i is even.  Every search of a game is evaluated by the network of the side to move; each

@@ -655,6 +655,12 @@ int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_ro
     (void)hipSetDevice(sp->device);
     if (sp->cfg.arena_mode) { m0_set_error("the external-evaluator step serves self-play engines only"); return M0_ERR_STATE; }
     if (sp->ext_pending) { m0_set_error("m0_selfplay_ext_expand outstanding"); return M0_ERR_STATE; }
+    // select applies virtual losses and reserves batch rows: refuse a buffer that cannot take the worst case BEFORE it runs
+    // (an error after it would leave the engine waiting for an ext_expand the caller has no planes for)
+    if (!planes || max_rows < sp->G * (sp->L + 1)) {
+        m0_set_error("planes buffer too small: concurrent_games * (inference_batch_size + 1) rows are required");
+        return M0_ERR_INVALID;
+    }
     int rc = start_first_games(sp);
     if (rc != M0_OK) return rc;
     int r = 0;
@@ -664,7 +670,6 @@ int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_ro
     sp->last_rows = r;
     sp->ext_pending = true;
     if (r > 0) {
-        if (!planes || r > max_rows) { m0_set_error("planes buffer too small"); return M0_ERR_INVALID; }
         if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
         (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * (sp->L + 1), hipMemcpyDeviceToHost);
         for (int g = 0; g < sp->G; ++g) {
@@ -877,6 +882,43 @@ int m0_encode_fens(int hip_device, const char* const* fens, int n, float* planes
     }
     if (dp) (void)hipFree(dp); if (dpl) (void)hipFree(dpl); if (dm) (void)hipFree(dm);
     if (dn) (void)hipFree(dn); if (dmv) (void)hipFree(dmv); if (di) (void)hipFree(di);
+    return rc;
+}
+
+int m0_selfplay_last_batch_nhwc(m0_selfplay* sp, uint16_t* out, int max_rows, int* rows) {
+    if (!sp || !out || !rows) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    (void)hipSetDevice(sp->device);
+    const int r = sp->last_rows;
+    if (r > max_rows) { m0_set_error("output buffer too small"); return M0_ERR_INVALID; }
+    *rows = r;
+    if (r > 0) {
+        if (hipMemcpyAsync(out, sp->d.x0, (size_t)r * 64 * 32 * 2, hipMemcpyDeviceToHost, sp->stream) != hipSuccess ||
+            hipStreamSynchronize(sp->stream) != hipSuccess) { m0_set_error("copy failed"); return M0_ERR_HIP; }
+    }
+    return M0_OK;
+}
+
+int m0_encode_fens_nhwc(int hip_device, const char* const* fens, int n, uint16_t* out) {
+    if (!fens || n <= 0 || !out) { m0_set_error("invalid argument"); return M0_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { m0_set_error("no HIP device available (no CPU fallback)"); return M0_ERR_HIP; }
+    if (hipSetDevice(hip_device) != hipSuccess) { m0_set_error("hipSetDevice failed"); return M0_ERR_HIP; }
+    std::vector<Pos> hp(n);
+    for (int i = 0; i < n; ++i)
+        if (!fens[i] || parse_fen(fens[i], hp[i]) != 0) { m0_set_error(std::string("bad FEN at index ") + std::to_string(i)); return M0_ERR_INVALID; }
+    Pos* dp = nullptr; _Float16* dx = nullptr;
+    int rc = M0_OK;
+    if (hipMalloc((void**)&dp, sizeof(Pos) * n) != hipSuccess || hipMalloc((void**)&dx, (size_t)n * 64 * 32 * 2) != hipSuccess) {
+        m0_set_error("hipMalloc failed"); rc = M0_ERR_HIP;
+    } else {
+        (void)hipMemcpy(dp, hp.data(), sizeof(Pos) * n, hipMemcpyHostToDevice);
+        if (launch_encode_positions(dp, n, nullptr, dx, nullptr, nullptr, nullptr, nullptr, nullptr) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) { m0_set_error("encode kernel failed"); rc = M0_ERR_HIP; }
+        else (void)hipMemcpy(out, dx, (size_t)n * 64 * 32 * 2, hipMemcpyDeviceToHost);
+    }
+    if (dp) (void)hipFree(dp);
+    if (dx) (void)hipFree(dx);
     return rc;
 }
 

@@ -73,6 +73,8 @@ def _bind():
     L.m0_selfplay_set_openings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), c_int]
     L.m0_selfplay_ext_select.argtypes = [C.c_void_p, C.POINTER(c_int), C.c_void_p, c_int]
     L.m0_selfplay_ext_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int]
+    L.m0_selfplay_last_batch_nhwc.argtypes = [C.c_void_p, C.c_void_p, c_int, C.POINTER(c_int)]
+    L.m0_encode_fens_nhwc.argtypes = [c_int, C.POINTER(C.c_char_p), c_int, C.c_void_p]
     L.m0_search_begin.argtypes = [C.c_void_p, c_int, C.c_char_p, c_int, c_int, c_int]
     L.m0_search_select.argtypes = [C.c_void_p, C.POINTER(c_int), C.c_void_p, c_int]
     L.m0_search_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int]
@@ -262,6 +264,16 @@ class SelfplayEngine:
         _lib.check(self._L.m0_selfplay_ext_expand(self._h, lg.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p),
                                                   int(lg.shape[0])), "m0_selfplay_ext_expand")
 
+    def last_batch_nhwc(self) -> np.ndarray:
+        """The network batch the last select wrote on the device (what `step()` feeds the network): f16 [rows,64,32],
+        row r = position r of the planes that select returned, channels 19..31 zero."""
+        cap = self.cfg.concurrent_games * (self.cfg.inference_batch_size + 1) + 4
+        out = np.zeros((cap, 64, 32), dtype=np.float16)
+        rows = c_int(0)
+        _lib.check(self._L.m0_selfplay_last_batch_nhwc(self._h, out.ctypes.data_as(C.c_void_p), cap, C.byref(rows)),
+                   "m0_selfplay_last_batch_nhwc")
+        return out[: rows.value]
+
     # ---- split-step search ----
     def search_begin(self, g: int, fen: str, sims: int, dirichlet: bool, game_uid: int) -> None:
         _lib.check(self._L.m0_search_begin(self._h, g, fen.encode(), sims, int(dirichlet), game_uid), "m0_search_begin")
@@ -419,6 +431,24 @@ def rules_probe(cfg: SelfplayCfg, fen: str, ucis: List[str]) -> dict:
     _lib.check(L.m0_rules_probe(C.byref(cfg), fen.encode(), arr, len(ucis), C.byref(flags), C.byref(res)), "m0_rules_probe")
     out = {name: bool(flags.value >> i & 1) for i, name in enumerate(RULE_FLAGS)}
     out["result"] = float(res.value)
+    return out
+
+
+def encode_fens_nhwc(fens, device_index: int = 0) -> np.ndarray:
+    """encode_board (encoding.py:11-46) as the search's select kernel writes it for the network: f16 [n,64,32]."""
+    L = _bind()
+    n = len(fens)
+    arr = (C.c_char_p * n)(*[f.encode() for f in fens])
+    out = np.empty((n, 64, 32), np.float16)
+    _lib.check(L.m0_encode_fens_nhwc(int(device_index), arr, n, out.ctypes.data_as(C.c_void_p)), "m0_encode_fens_nhwc")
+    return out
+
+
+def planes_to_nhwc(planes: np.ndarray) -> np.ndarray:
+    """f32 [n,19,8,8] -> the network's input layout f16 [n,64,32] (zero-padded channels)."""
+    p = np.asarray(planes, np.float32)
+    out = np.zeros((p.shape[0], 64, 32), np.float16)
+    out[:, :, :19] = p.reshape(p.shape[0], 19, 64).transpose(0, 2, 1).astype(np.float16)
     return out
 
 

@@ -90,3 +90,18 @@ def test_device_encoding_matches_reference_outputs(gold):
             assert enc.move_to_index(fens[i], uci(int(c))) == int(want_idx)
     with pytest.raises(ValueError):
         enc.move_to_index(ch.START_FEN, "e2e5")
+
+
+@pytest.mark.gpu
+def test_network_input_of_the_search_matches_reference_outputs(gold):
+    """The network input of the TIMED path: csrc/tree.hip::encode_nhwc, the device function select_kernel calls for every
+    leaf (fp16, NHWC [64 squares][32 channels]), run on every position of the golden file through m0_encode_fens_nhwc and
+    compared with fp16(encode_board of the reference) bit for bit -- channels 19..31 must be zero."""
+    from matrix0_amd import engine as eng
+    fens = gold["fens"]
+    got = eng.encode_fens_nhwc(fens)
+    assert got.shape == (len(fens), 64, 32) and got.dtype == np.float16
+    want = eng.planes_to_nhwc(np.stack([planes_from_bits(gold["plane_bits"][i], gold["counters"][i]) for i in range(len(fens))]))
+    bad = np.nonzero((got.view(np.uint16) != want.view(np.uint16)).any(axis=(1, 2)))[0]
+    assert bad.size == 0, fens[int(bad[0])]
+    assert not got[:, :, 19:].any()

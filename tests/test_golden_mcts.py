@@ -180,3 +180,65 @@ def test_table_across_moves_reference_raises_oracle_shows_zero_visits():
     b.push(max(vc, key=vc.get))
     vc, _, _ = o.run(b, num_simulations=64, ply=1)
     assert sum(vc.values()) == 0 and o._last_root.n == 64
+
+
+# ---- virtual loss: the reference's own lines (mcts.py:851, 889-890, 922-923), executed by tools/gen_golden_mcts.py::VLOn ----
+GV = load_json("ref_mcts_vl.json.gz")
+
+
+def test_select_one_level_with_inflight_counts_matches_reference():
+    """MCTS._select(board, root, inflight_counts=d) of the reference on hand-set statistics and a hand-set dict: which child
+    wins under the penalty `count * virtual_loss`, and that the chosen edge's count goes up by one."""
+    assert GV["fens"] == FENS
+    n_pen = 0
+    for c in GV["select_one_level"]["cases"]:
+        b = ch.Board(FENS[c["fen"]])
+        o = ref.MCTS(ref.MCTSConfig.from_dict(dict(BASE, selection_jitter=c["jitter"], fpu_reduction=c["fpu_reduction"],
+                                                   virtual_loss=c["virtual_loss"], use_tt=False)), None,
+                     seed=GV["select_one_level"]["seed"], game=c["uid"])
+        parent = ref.Node(); parent.n = c["parent_n"]; parent.q = c["parent_q"]; parent.expanded = True
+        kids = []
+        for m, (n, q, p) in zip(b.legal_moves, c["children"]):
+            k = ref.Node(prior=p, move=m, parent=parent); k.n = n; k.q = q
+            parent.children[m] = k
+            kids.append(k)
+        infl = {k: v for k, v in zip(kids, c["inflight"]) if v}
+        node, path, _ = o.select(b.copy(), parent, infl)
+        assert kids.index(path[1]) == c["chosen"], c["uid"]
+        assert [infl.get(k, 0) for k in kids] == c["inflight_after"]
+        assert o.jitter.ctr == c["draws"]
+        # without the dict the oracle must pick differently in some cases, or the cases pin nothing
+        o2 = ref.MCTS(ref.MCTSConfig.from_dict(dict(BASE, selection_jitter=c["jitter"], fpu_reduction=c["fpu_reduction"],
+                                                    use_tt=False)), None, seed=GV["select_one_level"]["seed"], game=c["uid"])
+        _, path2, _ = o2.select(b.copy(), parent, None)
+        n_pen += kids.index(path2[1]) != c["chosen"]
+    assert n_pen >= 10
+
+
+def _oracle_run_vl(case, numerics="reference"):
+    cfg = ref.MCTSConfig.from_dict(dict(BASE, **case["mcts_extra"], inference_batch_size=case["L"], use_tt=(case["tt"] == "on"),
+                                        virtual_loss_active=True, numerics=numerics))
+    net = HashNet(**case["net"])
+    o = ref.MCTS(cfg, net.infer_np, seed=case["seed"], game=case["uid"])
+    vc, pi, rq = o.run(ch.Board(FENS[case["fen"]]), num_simulations=case["sims"], ply=(0 if case["dirichlet"] else 1000))
+    return o, net, (_snap(o._last_root), vc, pi, rq, o._last_sims_run)
+
+
+@pytest.mark.parametrize("tt", ["off", "on"])
+@pytest.mark.parametrize("numerics,tol", [("reference", 1e-7), ("engine", 1e-6)])
+def test_whole_searches_with_virtual_loss_match_reference(tt, numerics, tol):
+    """MCTS.run with the batch's in-flight dict handed to _select (VLOn): 96 ... 1 600 simulations, batches of 16 / 32 / 96
+    (bench.py's search shape: 800 simulations, 96 leaves per batch), virtual_loss 0 / 0.3 / 1 / 3, Dirichlet on, terminal
+    leaves inside a batch, pruning; tree-only and with the table on.  The oracle with virtual_loss_active=True must give
+    identical visit counts, policy targets, evaluation counts and stream positions."""
+    n = n_differs = 0
+    for case in GV["runs"]:
+        if case["tt"] != tt:
+            continue
+        o, net, (root, vc, pi, rq, sims) = _oracle_run_vl(case, numerics)
+        _check_root(root, vc, pi, rq, sims, case["results"][0], tol)
+        assert net.calls == case["evals"], case["name"]
+        assert (o.jitter.ctr, o.noise.ctr, o.dirichlet.ctr) == (case["draws"]["jitter"], case["draws"]["noise"], case["draws"]["dirichlet"])
+        n += 1
+        n_differs += bool(case["differs_from_vl_off"])
+    assert n >= 22 and n_differs >= n - 1          # every case but virtual_loss = 0 is a search the penalty changed

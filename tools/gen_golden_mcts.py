@@ -25,7 +25,8 @@ children (mcts.py:344-358) while every grandchild is registered (mcts.py:654-666
 bypassed at mcts.py:919 and keep n == 0.
 
 Outputs (data only): tests/golden/ref_encoding.npz, ref_mcts.json.gz, ref_selfplay.json.gz, ref_worker_<name>.npz
-Usage: python tools/gen_golden_mcts.py [encoding] [mcts] [selfplay] [worker]     (default: all)
+         ref_mcts_vl.json.gz (the reference's own virtual-loss lines executed: class VLOn)
+Usage: python tools/gen_golden_mcts.py [encoding] [mcts] [mcts_vl] [selfplay] [worker]     (default: all)
 """
 from __future__ import annotations
 
@@ -153,6 +154,58 @@ class TTOff:
 
     def __exit__(self, *a):
         rmcts.MCTS._tt_get = self.saved
+
+
+class VLOn:
+    """Virtual loss exactly as the reference wrote it and never calls it.  MCTS._select takes `inflight_counts` and applies /
+    maintains it (mcts.py:851, 889-890, 922-923), but its only callers (_collect_leaf_position mcts.py:745, _run_simulation
+    :777) never pass one.  This patch passes one -- a dict that lives for ONE batch of _run_simulations_parallel_batched
+    (mcts.py:535-558: batch k of a run() = calls k*L .. k*L+batch_n-1 of _collect_leaf_position) -- and changes nothing else:
+    _select's body, the batch loop, expansion and backup are the reference's own code."""
+
+    def __enter__(self):
+        self.saved = (rmcts.MCTS._select, rmcts.MCTS._collect_leaf_position, rmcts.MCTS._run_simulations_parallel_batched)
+        o_select, o_collect, o_batched = self.saved
+
+        def select(self_, board, root, inflight_counts=None, base_ply=0):
+            if inflight_counts is None:
+                inflight_counts = getattr(self_, "_m0_inflight", None)
+            return o_select(self_, board, root, inflight_counts=inflight_counts, base_ply=base_ply)
+
+        def collect(self_, board, root, leaf_samples, append_lock):
+            L = int(getattr(self_.cfg, "inference_batch_size", None) or getattr(self_.cfg, "simulation_batch_size", 96))
+            if self_._m0_calls % L == 0:
+                self_._m0_inflight = {}
+            self_._m0_calls += 1
+            return o_collect(self_, board, root, leaf_samples, append_lock)
+
+        def batched(self_, board, root, num_simulations):
+            self_._m0_calls = 0
+            self_._m0_inflight = {}
+            try:
+                return o_batched(self_, board, root, num_simulations)
+            finally:
+                self_._m0_inflight = None
+
+        rmcts.MCTS._select, rmcts.MCTS._collect_leaf_position, rmcts.MCTS._run_simulations_parallel_batched = select, collect, batched
+        return self
+
+    def __exit__(self, *a):
+        rmcts.MCTS._select, rmcts.MCTS._collect_leaf_position, rmcts.MCTS._run_simulations_parallel_batched = self.saved
+
+
+class Both:
+    def __init__(self, *cms):
+        self.cms = cms
+
+    def __enter__(self):
+        for c in self.cms:
+            c.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        for c in reversed(self.cms):
+            c.__exit__(*a)
 
 
 class Nop:
@@ -378,13 +431,116 @@ def gen_mcts():
     dump_json("ref_mcts.json.gz", out)
 
 
+# ------------------------------------------------------------------------------------------------ B2. virtual loss
+def gen_mcts_vl():
+    """ref_mcts_vl.json.gz: the reference's own virtual-loss lines executed (class VLOn)."""
+    out = {"base_mcts": BASE_MCTS, "fens": FENS}
+
+    # -- _select, one level, with a hand-set inflight_counts dict (mcts.py:889-890 penalty, :922-923 bookkeeping)
+    sel = []
+    rng = np.random.default_rng(15)
+    for k in range(60):
+        fi = k % len(FENS)
+        b = chess.Board(FENS[fi])
+        legal = list(b.legal_moves)
+        parent = rmcts.Node()
+        parent.n = int(rng.integers(0, 400)); parent.q = float(rng.uniform(-0.8, 0.8)); parent.w = parent.q * parent.n
+        parent.expanded = True
+        pri = rng.dirichlet([0.5] * len(legal))
+        stats, kids = [], []
+        for m, p in zip(legal, pri):
+            c = rmcts.Node(prior=float(p), move=m, parent=parent)
+            if rng.random() < 0.5:
+                c.n = int(rng.integers(1, 60)); c.q = float(rng.uniform(-1, 1)); c.w = c.q * c.n
+            parent.children[m] = c
+            kids.append(c)
+            stats.append([c.n, c.q, float(p)])
+        vloss = [1.0, 0.3, 3.0, 0.0][k % 4]
+        jit = [0.05, 0.0, 0.01][k % 3]
+        # in-flight counts concentrated on the children that would otherwise win
+        infl = {}
+        order = np.argsort([-(st[1] if st[0] else parent.q) - 2.5 * st[2] * np.sqrt(max(1, parent.n)) / (1 + st[0]) for st in stats])
+        for j in order[: int(rng.integers(0, 5))]:
+            infl[kids[int(j)]] = int(rng.integers(1, 6))
+        before = [int(infl.get(c, 0)) for c in kids]
+        mc = new_mcts(dict(BASE_MCTS, selection_jitter=jit, fpu_reduction=[0.1, 0.3][k % 2], virtual_loss=vloss), None)
+        st = refshim.Streams(556, k)
+        with TTOff(), refshim.injected(st):
+            node, path, _ = mc._select(b.copy(), parent, inflight_counts=infl)
+        chosen = kids.index(path[1])
+        sel.append({"fen": fi, "uid": k, "parent_n": parent.n, "parent_q": parent.q, "children": stats, "jitter": jit,
+                    "fpu_reduction": [0.1, 0.3][k % 2], "virtual_loss": vloss, "inflight": before,
+                    "inflight_after": [int(infl.get(c, 0)) for c in kids], "chosen": chosen, "draws": st.jitter.ctr})
+    out["select_one_level"] = {"seed": 556, "cases": sel}
+    n_diff = 0
+    for c in sel:                                            # the cases must actually exercise the penalty
+        n_diff += int(c["inflight"][c["chosen"]] == 0 and any(c["inflight"]))
+    print("select_one_level: chosen child had no in-flight count while others had in", n_diff, "of", len(sel), "cases")
+
+    # -- whole MCTS.run with the batch dict
+    runs = []
+
+    def run_case(name, fen_i, sims, L, tt, seed, uid, net_kw, extra=None, dirichlet=True, repeats=1):
+        mcfg = dict(BASE_MCTS, inference_batch_size=L, **(extra or {}))
+        net = HashNet(**net_kw)
+        mc = new_mcts(mcfg, net)
+        b = chess.Board(FENS[fen_i])
+        st = refshim.Streams(seed, uid)
+        res = []
+        with Both(TTOff() if tt == "off" else Nop(), VLOn()), refshim.injected(st):
+            for r in range(repeats):
+                vc, pi, rq = mc.run(b, num_simulations=sims, ply=(0 if dirichlet else 1000))
+                res.append(root_dump(mc, vc, pi, rq))
+        # the same search WITHOUT the dict, for the record: virtual loss must change the visit distribution
+        mc0 = new_mcts(mcfg, HashNet(**net_kw))
+        with (TTOff() if tt == "off" else Nop()), refshim.injected(refshim.Streams(seed, uid)):
+            vc0, _, _ = mc0.run(chess.Board(FENS[fen_i]), num_simulations=sims, ply=(0 if dirichlet else 1000))
+        differs = [int(v) for v in vc0.values()] != res[0]["n"]
+        runs.append({"name": name, "fen": fen_i, "sims": sims, "L": L, "tt": tt, "seed": seed, "uid": uid, "net": net_kw,
+                     "mcts_extra": extra or {}, "dirichlet": dirichlet, "repeats": repeats, "results": res, "model_path": False,
+                     "evals": net.calls, "tt_entries": len(mc.tt), "differs_from_vl_off": differs,
+                     "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
+        print("vl run", name, "fen", fen_i, "sims", sims, "L", L, "tt", tt, "evals", net.calls, "root_n", res[-1]["root_n"],
+              "differs from vl-off:", differs, flush=True)
+
+    uid = 3000
+    for tt in ("off", "on"):
+        for fi in range(len(FENS)):
+            uid += 1
+            run_case("basic16", fi, 96, 16, tt, 1234, uid, {"seed": 3, "sharp": 8.0})
+        for fi in (0, 1, 3, 7):
+            uid += 1
+            run_case("batch96", fi, 96 * 3, 96, tt, 1234, uid, {"seed": 4, "sharp": 10.0})
+        uid += 1
+        run_case("long_1600_L96", 0, 1600, 96, tt, 1234, uid, {"seed": 22, "sharp": 14.0})
+        uid += 1
+        run_case("long_1600_L16", 1, 1600, 16, tt, 1234, uid, {"seed": 21, "sharp": 10.0},
+                 extra={"cpuct_c_base": 19652.0, "cpuct_c_init": 1.25})
+        uid += 1
+        run_case("bench_800_L96", 3, 800, 96, tt, 1234, uid, {"seed": 23, "sharp": 6.0})       # the bench's search shape
+        uid += 1
+        run_case("vloss_0.3", 1, 200, 32, tt, 1234, uid, {"seed": 5, "sharp": 12.0}, extra={"virtual_loss": 0.3})
+        uid += 1
+        run_case("vloss_3_nodir", 7, 200, 32, tt, 1234, uid, {"seed": 6, "sharp": 4.0}, extra={"virtual_loss": 3.0}, dirichlet=False)
+        uid += 1
+        run_case("vloss_zero", 0, 96, 16, tt, 1234, uid, {"seed": 7, "sharp": 8.0}, extra={"virtual_loss": 0.0})
+        uid += 1
+        run_case("mate_in_reach", 5, 128, 32, tt, 1234, uid, {"seed": 8, "sharp": 2.0})            # terminal leaves keep their counts
+        uid += 1
+        run_case("prune_topk", 1, 128, 16, tt, 1234, uid, {"seed": 31, "sharp": 8.0}, extra={"max_children": 6})
+    out["runs"] = runs
+    dump_json("ref_mcts_vl.json.gz", out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["encoding", "mcts", "selfplay", "worker"]
+    what = sys.argv[1:] or ["encoding", "mcts", "mcts_vl", "selfplay", "worker"]
     os.makedirs(OUT, exist_ok=True)
     if "encoding" in what:
         gen_encoding()
     if "mcts" in what:
         gen_mcts()
+    if "mcts_vl" in what:
+        gen_mcts_vl()
     if "selfplay" in what:
         from gen_golden_selfplay import gen_selfplay
         gen_selfplay()
