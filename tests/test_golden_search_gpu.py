@@ -1,8 +1,10 @@
 """The HIP search kernels compared DIRECTLY with traces of the real reference code (tests/golden/ref_mcts.json.gz, produced by
 running /root/reference/azchess/mcts.py: see tools/gen_golden_mcts.py) -- no oracle in between.  Same counter streams, same
-bit-reproducible evaluator (tests/hash_net.py) fed through the split-step C-ABI.  The reference has no virtual loss and, in
-its transposition table is either patched out (tree-only: the engine's default structure) or left on (the engine's
-compat.tt_merge); the engine runs with virtual_loss_active=0 throughout.
+bit-reproducible evaluator (tests/hash_net.py) fed through the split-step C-ABI.  The reference's transposition table is
+either patched out (tree-only: the engine's default structure) or left on (the engine's compat.tt_merge).  Its run() never
+hands _select an in-flight dict, so ref_mcts.json.gz is compared with virtual_loss_active=0; ref_mcts_vl.json.gz holds the
+traces in which it does (the reference's own virtual-loss lines executed) and is compared with virtual_loss_active=1, the
+mode bench.py times.
 
 Integer results (move order, policy indices, visit counts, simulations) must be identical; float32 priors within 1e-6
 (the tolerance of the reference's own tests/test_mcts_logits.py); float64 q / root value within 1e-9."""
@@ -17,11 +19,11 @@ G = load_json("ref_mcts.json.gz")
 FENS, BASE = G["fens"], G["base_mcts"]
 
 
-def _engine(mcts, seed, L, compat=None, sims=96):
+def _engine(mcts, seed, L, compat=None, sims=96, vl=False):
     from matrix0_amd import engine as eng
     # num_simulations sizes the node arena (one search of new children): give it the search length
     cfg = eng.selfplay_cfg_from_dict({"seed": seed, "mcts": dict(mcts, inference_batch_size=L), "selfplay": {"num_simulations": sims}},
-                                     concurrent_games=1, virtual_loss_active=False, compat=compat)
+                                     concurrent_games=1, virtual_loss_active=vl, compat=compat)
     return eng.SelfplayEngine(None, cfg)
 
 
@@ -76,6 +78,38 @@ def test_whole_searches_match_reference_traces(tt):
         e.close()
         n += 1
     assert n >= 30
+
+
+@pytest.mark.parametrize("tt", ["off", "on"])
+def test_whole_searches_with_virtual_loss_match_reference_traces(tt):
+    """bench.py's search mode (virtual_loss_active = 1) against the reference's OWN virtual-loss lines: tests/golden/
+    ref_mcts_vl.json.gz holds MCTS.run traces in which _collect_leaf_position hands _select the batch's in-flight dict
+    (mcts.py:851, 889-890, 922-923; tools/gen_golden_mcts.py::VLOn).  96 ... 1 600 simulations, 16 / 32 / 96 leaves per batch
+    (incl. the bench shape: 800 simulations in batches of 96), virtual_loss 0 / 0.3 / 1 / 3, terminal leaves inside a batch,
+    pruning.  Identical visit counts, evaluation counts and policy targets."""
+    GV = load_json("ref_mcts_vl.json.gz")
+    assert GV["fens"] == FENS
+    n = 0
+    for case in GV["runs"]:
+        if case["tt"] != tt:
+            continue
+        mcts = dict(GV["base_mcts"], **case["mcts_extra"])
+        want = case["results"][0]
+        e = _engine(mcts, case["seed"], case["L"], sims=want["sims"], vl=True, compat={"tt_merge": tt == "on"})
+        net = HashNet(**case["net"])
+        e.search_begin(0, FENS[case["fen"]], want["sims"], case["dirichlet"], case["uid"])
+        res = _search(e, net)
+        _compare(res, want)
+        assert net.calls == case["evals"], case["name"]
+        pi = np.zeros(4672, np.float32)
+        tot = int(res["n"].sum())
+        for i, k in zip(res["idx"], res["n"]):
+            pi[i] = np.float32(int(k) / tot)
+        nz = np.nonzero(pi)[0]
+        assert nz.tolist() == want["pi_idx"] and [float(pi[j]) for j in nz] == want["pi_val"]
+        e.close()
+        n += 1
+    assert n >= 22
 
 
 def test_reused_root_is_evaluated_again_unless_cached():

@@ -135,7 +135,8 @@ def test_oracle_replays_reference_worker_games(name):
     meta = g["meta"]
     net = HashNet(**meta["net"])
     out = selfplay_ref.play_game(worker_cfg(meta), net.infer_np, meta["seed"], 0, book=meta["book"] or None,
-                                 use_tt=False, tree_reuse=False, virtual_loss_active=False, numerics="reference")
+                                 use_tt=False, tree_reuse=False, virtual_loss_active=bool(meta.get("virtual_loss_active", False)),
+                                 numerics="reference")
     check_game_against_golden(out, g, evals=net.calls)
     assert out["streams"] == meta["draws"]
 

@@ -1,6 +1,7 @@
 """WHOLE GAMES on the HIP engine compared directly with the games the reference's own selfplay_worker produced
 (tests/golden/ref_worker_*.npz, tools/gen_golden_selfplay.py): same seed, same counter streams, same evaluator (tests/hash_net.py
-behind the external-evaluator step of the C-ABI), reference mode = no virtual loss, a fresh tree per move (its transposition
+behind the external-evaluator step of the C-ABI), reference mode = a fresh tree per move, no virtual loss -- except `vl_on_batch96`, played by the reference with its own
+virtual-loss lines executed (tools/gen_golden_mcts.py::VLOn) and by the engine with virtual_loss_active=1 -- (its transposition
 table patched out: with the table on the reference cannot get past move 2, see ref_mcts.json.gz::tt_across_moves).
 
 Everything a shard contains must agree: planes, policy targets, legal masks, value targets, result, resignation, draw flag,
@@ -20,8 +21,8 @@ def _play(meta, net):
     cfg_dict = worker_cfg(meta)
     vfw = bool(cfg_dict["mcts"].get("value_from_white", False)) or detect_value_from_white(net)     # internal.py:245-247
     cfg_dict["mcts"] = dict(cfg_dict["mcts"], value_from_white=vfw)
-    cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=1, total_games=1, first_game_index=0, virtual_loss_active=False,
-                                     ssl_targets=meta["ssl"], compat={"fresh_tree_per_move": True})
+    cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=1, total_games=1, first_game_index=0,
+                                     virtual_loss_active=bool(meta.get("virtual_loss_active", False)), ssl_targets=meta["ssl"], compat={"fresh_tree_per_move": True})
     e = eng.SelfplayEngine(None, cfg)
     if meta["book"]:
         e.set_openings(meta["book"])

@@ -51,7 +51,7 @@ import azchess.selfplay.internal as rsp  # noqa: E402
 from oracle import chess_py as ch  # noqa: E402
 from oracle import mcts_ref as oref  # noqa: E402
 from tests.hash_net import HashNet  # noqa: E402
-from gen_golden_mcts import BASE_MCTS, FENS, OUT, TTOff, dump_json, mv_code  # noqa: E402
+from gen_golden_mcts import BASE_MCTS, FENS, OUT, Both, Nop, TTOff, VLOn, dump_json, mv_code  # noqa: E402
 
 logging.disable(logging.CRITICAL)
 
@@ -244,7 +244,18 @@ WORKER_CASES = {
                          "draw": {"enabled": True, "min_plies": 8, "window": 8, "min_unique": 4, "halfmove_cap": 16,
                                   "material_draw_threshold": 8}},
                         {"inference_batch_size": 8}, ["4k3/8/8/8/3n4/8/3N4/4K2R w - - 0 1"], False),
+    # the length of a real self-play game at the reference's own leaf batch (mcts.inference_batch_size = 96, config.yaml:157)
+    "lengthcap200_batch96": (4242, {"seed": 17, "sharp": 6.0, "vscale": 0.5},
+                             {"num_simulations": 96, "max_game_len": 200, "opening_random_plies": 12, "temperature_start": 1.0,
+                              "temperature_end": 0.1, "temperature_moves": 20, "resign_threshold": -0.98, "min_resign_plies": 24},
+                             {"inference_batch_size": 96}, None, False),
+    # virtual loss ON: the reference's own lines (mcts.py:889-890, 922-923) executed for a whole game (gen_golden_mcts.VLOn)
+    "vl_on_batch96": (99, {"seed": 19, "sharp": 7.0, "vscale": 0.5},
+                      {"num_simulations": 192, "max_game_len": 40, "opening_random_plies": 4, "temperature_start": 1.0,
+                       "temperature_end": 0.3, "temperature_moves": 30, "resign_threshold": -0.98, "min_resign_plies": 24},
+                      {"inference_batch_size": 96, "playout_random_frac": 0.1}, None, False),
 }
+WORKER_VL = {"vl_on_batch96"}
 
 
 def run_worker_case(name):
@@ -284,7 +295,7 @@ def run_worker_case(name):
     rsp.sample_move_from_counts = sample_wrap
     st = refshim.Streams(seed, 0)
     try:
-        with TTOff(), refshim.injected(st):
+        with Both(TTOff(), VLOn() if name in WORKER_VL else Nop()), refshim.injected(st):
             rsp.selfplay_worker(0, cfg, None, 1, q, {"fake": True})
     finally:
         rsp.select_device, rsp.InferenceClient, rsp.OPENING_BOOK = saved
@@ -302,6 +313,7 @@ def run_worker_case(name):
     assert len(trace["visits"]) == T
     meta = {"name": name, "seed": seed, "net": net_kw, "selfplay": sp, "mcts": mcts, "book": book or [], "ssl": bool(ssl),
             "npz_keys": sorted(z.files), "evals": net.calls,
+            "virtual_loss_active": name in WORKER_VL,
             "message": {k: (v if not isinstance(v, float) else float(v)) for k, v in game.items() if k not in ("file", "secs", "avg_ms_per_move")},
             "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}}
     # planes are 0/1 except the two counter planes -> keep float32 as written; zlib shrinks them well
