@@ -72,6 +72,16 @@ def game_length_basis():
         return DEFAULT_PLIES_PER_GAME, "default (no calibration file)"
 
 
+def generation_passes_per_ply():
+    """Passes of the hot path per searched ply and game over a WHOLE generation played to completion (games finish at different
+    times and their searches drift apart, so a pass serves searches at different stages): tools/calibrate_game_length.py."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "game_length.json")))
+        return d.get("passes_per_ply"), d.get("games_per_s_end_to_end")
+    except Exception:
+        return None, None
+
+
 def host_cores() -> int:
     """CPUs this process may use: scheduler affinity, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0))
@@ -124,13 +134,21 @@ def cpu_baseline(seconds: float, plies_per_game: float, threads: int = 4):
     for p in procs:
         p.start()
     res = []
-    for _ in procs:
+    deadline = t0 + seconds * 6 + 300          # a worker checks its own clock once per searched ply; first import can take minutes
+    while len(res) < len(procs) and time.perf_counter() < deadline:
         try:
-            res.append(q.get(timeout=seconds * 6 + 300))
+            res.append(q.get(timeout=2.0))
         except Exception:
-            break
-    for p in procs:
-        p.join(timeout=30)
+            if all(p.exitcode is not None for p in procs) and q.empty():
+                break                          # every worker is gone (a crash reports nothing): do not wait out the deadline
+    for p in procs:                            # nothing of the baseline may still run when the GPU leg starts
+        p.join(timeout=5)
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+                p.join()
     wall = time.perf_counter() - t0
     if not res:
         return {"value": None, "unit": "games/s", "cores": cores, "kind": "port", "sample": "no worker reported"}
@@ -305,6 +323,12 @@ def main():
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "passes_per_step": passes / max(1, args.steps), "ms_per_pass": dt_max * 1e3 / passes,
+            # the timed region is the friendliest regime: all resident searches are in step, so every pass is a full batch and a
+            # ply costs ceil(sims / leaves) passes.  Over a whole generation the searches drift apart (games end at different
+            # plies; playout caps differ): `whole_generation` is what tools/calibrate_game_length.py measured end to end
+            "passes_per_ply": {"in_step_timed_region": passes / max(1, args.steps),
+                               "whole_generation": generation_passes_per_ply()[0],
+                               "whole_generation_games_per_s_end_to_end": generation_passes_per_ply()[1]},
             "time_split_ms_per_pass": {"net": ms_net / args.gpus / passes, "tree": ms_tree / args.gpus / passes,
                                        "host": ms_host / args.gpus / passes},
             "roofline": {"bound": "mfma", "kernel": "conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped, MFMA 16x16x32 f16)",

@@ -181,6 +181,7 @@ typedef struct m0_selfplay_stats {
     uint64_t steps, evals, sims, plies, games_finished, games_started;
     double ms_total, ms_net, ms_tree, ms_host;   /* accumulated wall (host) and device (HIP events) times */
     uint64_t arena_overflows;
+    uint64_t ssl_dropped;         /* finished games emitted WITHOUT ssl_* targets because their staging buffers could not grow */
     int active_games;
 } m0_selfplay_stats;
 

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     if (tid < 320) {
         float* par = reinterpret_cast<float*>(smem + AB_PAR);
         par[tid] = a.ln_g[tid]; par[320 + tid] = a.ln_b[tid];
-        par[640 + tid] = (a.y2 || a.out_gn) ? a.gn2_gamma[tid] : 0.f; par[960 + tid] = (a.y2 || a.out_gn) ? a.gn2_beta[tid] : 0.f;
+        par[640 + tid] = a.y2 ? a.gn2_gamma[tid] : 0.f; par[960 + tid] = a.y2 ? a.gn2_beta[tid] : 0.f;
     }
 
 #if AB_DBG == 3
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         }
     };
     flush(a.y);
-    if (a.y2 == nullptr && a.out_gn == nullptr) return;
+    if (a.y2 == nullptr) return;
     // ---- second output: act(GroupNorm16(y)) for the next residual block (statistics per board and 16-channel group)
     __syncthreads();
     if (tid < 40) {
@@ -394,14 +394,6 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                 scv[bd] = g2 * mr.y; shv[bd] = b2 - mr.x * scv[bd];
             }
         }
-        if (a.y2 == nullptr) {
-            // GroupNorm-on-load consumer: only (scale, shift) per (board, channel) leave the kernel, the next conv1 applies them
-            if (tid < 320) {
-                float2* o = reinterpret_cast<float2*>(a.out_gn) + (size_t)b0 * 320 + tid;
-                o[0] = make_float2(scv[0], shv[0]); o[320] = make_float2(scv[1], shv[1]);
-            }
-            return;
-        }
         __syncthreads();
         if (tid < 320) { parw[tid] = scv[0]; parw[320 + tid] = shv[0]; parw[640 + tid] = scv[1]; parw[960 + tid] = shv[1]; }
         __syncthreads();
@@ -426,16 +418,15 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
 hipError_t launch_attn_block(const AttnBlockArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.B % 2 != 0 || a.ln_count <= 0 || a.ln_count > 320) return hipErrorInvalidValue;
     if (a.y2 != nullptr && a.act != ACT_SILU && a.act != ACT_RELU) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_SILU>),
+    static DeviceOnce once;
+    hipError_t e = once.run([] {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_SILU>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_RELU>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+        if (r != hipSuccess) return r;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_block_kernel<ACT_RELU>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
+    });
+    if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(a.B / 2));
     if (a.act == ACT_RELU) hipLaunchKernelGGL(attn_block_kernel<ACT_RELU>, grid, dim3(512), AB_LDS, st, a);
     else hipLaunchKernelGGL(attn_block_kernel<ACT_SILU>, grid, dim3(512), AB_LDS, st, a);

@@ -55,12 +55,12 @@ m0_net* m0_net_create(const m0_net_cfg* cfg, int hip_device) {
     if (hipSetDevice(hip_device) != hipSuccess) { m0_set_error("hipSetDevice failed"); return nullptr; }
     m0_net* h = new m0_net();
     h->device = hip_device;
-    h->net = new Net(*cfg, hip_device);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         m0_set_error("hipStreamCreate failed");
-        delete h->net; delete h;
+        delete h;
         return nullptr;
     }
+    h->net = new Net(*cfg, hip_device, h->stream);
     return h;
 }
 

@@ -214,20 +214,19 @@ __global__ __launch_bounds__(256 * WNW) void conv_big_kernel(GemmArgs a) {
 template <int TAPS, int EPI, int WNW, int ACT = ACT_NONE>
 static hipError_t launch_conv_big_e(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW, ACT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<TAPS, EPI, WNW, ACT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     dim3 grid((a.Mrows / 256) * (a.Npad / 320), a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL((conv_big_kernel<TAPS, EPI, WNW, ACT>), grid, dim3(256 * WNW), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st) {
-    // 1x1 convs whose N is a multiple of 320 (qkv, proj).  3x3: conv_pp_kernel (conv_pp.hip).
+    // 1x1 convs whose N is a multiple of 320 (qkv, proj).  3x3: conv_zs_kernel / conv_pp16_kernel.
     // WNW = 2 (8 waves).  The 4-wave / 512-register form (WNW = 1) was built and measured: numerically identical,
     // 2x slower with hipcc's schedule (LDS latency exposed with one wave per SIMD, spills) -- not instantiated.
     if (taps != 1) return hipErrorInvalidValue;

@@ -1,4 +1,4 @@
-// Output epilogues of the 256x320 conv tile (shared by conv_big_kernel and conv_pp_kernel).
+// Output epilogues of the 256x320 conv tile (conv_big_kernel; the 32x32x16 3x3 experiment tools/ubench/conv_pp.hip uses them too).
 #pragma once
 #include "kernel_common.h"
 

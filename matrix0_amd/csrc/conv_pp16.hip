@@ -1,4 +1,4 @@
-// conv_pp16_kernel: the 3x3 320->320 implicit-GEMM conv of conv_pp.hip (same workgroup tile, LDS images, DMA ring, ping-pong
+// conv_pp16_kernel: the 3x3 320->320 implicit-GEMM conv of tools/ubench/conv_pp.hip (same workgroup tile, LDS images, DMA ring, ping-pong
 // groups and barrier protocol -- read its header) on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
 //
 // Why the shape matters: the main loop is POWER-bound, not issue-bound.  In-kernel stamps (tools/ubench, -DSW_STAMP, random
@@ -10,7 +10,7 @@
 // One phase pair per half-tile (32 k): a wave reads 4 activation fragments (16 squares x 32 k each) and 10 weight fragments
 // (16 channels x 32 k), then issues 40 MFMAs; accumulators = 4 x 10 tiles of 16 squares x 16 channels (160 registers).
 // Lane l = (c15 = l & 15, q = l >> 4): A fragment = row (square) c15 of the tile, k 8q..8q+7; B fragment = channel c15, same k.
-// LDS images as in conv_pp.hip; the weight rows' 16-byte chunk swizzle is  chunk ^ ((4 - (row >> 2)) & 3)  (pack_gemm), which is
+// LDS images as in tools/ubench/conv_pp.hip; the weight rows' 16-byte chunk swizzle is  chunk ^ ((4 - (row >> 2)) & 3)  (pack_gemm), which is
 // conflict-free for this read pattern and for the 32x32 one.
 #include "kernel_common.h"
 #include "conv_epilogue16.h"
@@ -26,27 +26,7 @@ __device__ __forceinline__ void p16_glds16(const void* gsrc, void* lds_wave_base
 __device__ unsigned long long* g_p16_stamp;     // [blocks][4]: s_memtime / s_memrealtime at main-loop start and end
 #endif
 
-// GroupNorm-on-load (TX): one 1-KiB piece of an activation chunk (8 squares x 64 channels, as the DMA laid it down) becomes
-// act(y * scale + shift) in place.  Lane = (row lane>>3 of the piece, 16-byte slot lane&7); the slot holds source chunk
-// slot ^ key(row) (the DMA's pre-swizzle), i.e. channels 8j..8j+7 of the 64-channel chunk; scale / shift per (board, channel)
-// come from the workgroup's LDS table.
-template <int ACT>
-__device__ __forceinline__ void p16_tx_piece(char* piece, int q, int chunk, const float2* tbl, int lane) {
-    const int p = 8 * q + (lane >> 3);
-    const int j = (lane & 7) ^ ((p >> 1) & 7);
-    const float4* t4 = reinterpret_cast<const float4*>(tbl + (p >> 6) * 320 + chunk * 64 + 8 * j);
-    half8* vp = reinterpret_cast<half8*>(piece + lane * 16);
-    const half8 v = *vp;
-    const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
-    half8 o;
-    o[0] = (_Float16)act_fast<ACT>((float)v[0] * t0.x + t0.y); o[1] = (_Float16)act_fast<ACT>((float)v[1] * t0.z + t0.w);
-    o[2] = (_Float16)act_fast<ACT>((float)v[2] * t1.x + t1.y); o[3] = (_Float16)act_fast<ACT>((float)v[3] * t1.z + t1.w);
-    o[4] = (_Float16)act_fast<ACT>((float)v[4] * t2.x + t2.y); o[5] = (_Float16)act_fast<ACT>((float)v[5] * t2.z + t2.w);
-    o[6] = (_Float16)act_fast<ACT>((float)v[6] * t3.x + t3.y); o[7] = (_Float16)act_fast<ACT>((float)v[7] * t3.z + t3.w);
-    *vp = o;
-}
-
-template <int EPI, int ACT, bool TX = false>
+template <int EPI, int ACT>
 __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
     constexpr int NG = 10, MT = 4;
     constexpr int A_BYTES = 256 * 128;    // 4 boards x 64 squares x 64 channels fp16, 128-byte rows
@@ -56,7 +36,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
     char* W_lds = smem + 2 * A_BYTES;     // [4][WH_BYTES]  half-tile y in slot y&3
     char* Z_lds = W_lds + 4 * WH_BYTES;   // one all-zero square (128 B)
     char* D_lds = Z_lds + 128;            // [4][1024] sink of the filler DMA pieces
-    float2* T_lds = reinterpret_cast<float2*>(D_lds + 4096);   // TX: [4 boards][320] (scale, shift) of the input's GroupNorm
 
 #ifdef SW_STAMP
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
@@ -114,13 +93,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
     }
 
     // ---- prologue: chunk 0 activations, half-tiles 0..2 ----
-    if constexpr (TX) {
-        // the (scale, shift) table of this tile's 4 boards: 10 KiB, contiguous in the producer's table -> 10 DMA pieces, issued
-        // first (oldest: retired by the same counted wait as the activations)
-        const char* tsrc = reinterpret_cast<const char*>(a.tx_table) + (size_t)(m0 / 64) * 2560 + lane * 16;
-        p16_glds16(tsrc + wave * 1024, reinterpret_cast<char*>(T_lds) + wave * 1024);
-        if (wave < 2) p16_glds16(tsrc + (8 + wave) * 1024, reinterpret_cast<char*>(T_lds) + (8 + wave) * 1024);
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_A_piece(0, wave * 4 + i);
     issue_half(0);
@@ -131,15 +103,9 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
     // __syncthreads() here would drain the DMA queue (vmcnt(0)).
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (TX) {                                 // chunk 0: every wave normalises the 4 pieces it brought in
-#pragma unroll
-        for (int i = 0; i < 4; ++i) p16_tx_piece<ACT>(A_lds + (wave * 4 + i) * 1024, wave * 4 + i, 0, T_lds, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
     if (wn == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
-    // ---- steady-state DMA (wave-uniform state, advanced incrementally; see conv_pp.hip) ----
+    // ---- steady-state DMA (wave-uniform state, advanced incrementally; see tools/ubench/conv_pp.hip) ----
     const uint32_t w_lane = (uint32_t)lane * 16u;
     const uint32_t a_lane = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u +
                             16u * (uint32_t)((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4)));   // piece q = 4 xi + wave - 4
@@ -203,11 +169,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
             static_for<0, 2>([&](auto h_) __attribute__((always_inline)) {
                 constexpr int h = decltype(h_)::value;
                 const int yh = y + h;
-                int txq = -1;                 // TX: the piece this wave normalises in this half-tile (below)
-                if constexpr (TX && G == 1) {
-                    const int k = 2 * tap + h - 3;
-                    if (k >= 0 && k < 8 && c + 1 < nchunk) txq = (wave - 4) + 4 * k;
-                }
                 half8 fa[MT], fb[NG];
                 const char* Wb = W_lds + (yh & 3) * WH_BYTES + wrow_off + 16 * wfx;
                 static_for<0, MT>([&](auto mi_) __attribute__((always_inline)) {
@@ -230,16 +191,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
                     });
                     if constexpr (ni == 2) { P16_FENCE(); issue_next(G_); P16_FENCE(); }
-                    if constexpr (TX && G == 1 && ni == 4) {
-                        // GroupNorm-on-load of the piece this wave issued three half-tiles ago (rows 8q.. of the NEXT chunk): it
-                        // has landed (the load sections' counted waits leave only the two youngest groups in flight) and its first
-                        // reader is a whole chunk away.  MEASURED NEGATIVE (round 2): one piece is ~70 VALU instructions (8 x
-                        // SiLU in fp32) and a v_mfma_f32_16x16x32 stream leaves the SIMD's vector issue only 8 of every 16 cycles,
-                        // so each transform costs ~830 cycles of matrix-pipe time wherever it is placed (load section, here, or
-                        // split over the MFMA groups without a branch): conv1 +45 us per launch against -31 us on the tail that no
-                        // longer writes y2.  Off by default (M0_CONV_TX=1 turns it on; tests/test_net_gpu.py keeps it correct).
-                        if (txq >= 0) p16_tx_piece<ACT>(A_lds + ((c + 1) & 1) * A_BYTES + txq * 1024, txq, c + 1, T_lds, lane);
-                    }
                 });
                 __builtin_amdgcn_s_setprio(0);
                 P16_FENCE();
@@ -260,7 +211,7 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tail refetches / fillers have landed
     if (wn == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
-    __builtin_amdgcn_s_barrier();                       // every wave's DMA has landed before anyone stages output (conv_pp.hip)
+    __builtin_amdgcn_s_barrier();                       // every wave's DMA has landed before anyone stages output (tools/ubench/conv_pp.hip)
 
 #ifdef SW_STAMP
     if (tid == 0) {
@@ -282,18 +233,17 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
 #endif
 }
 
-template <int EPI, int ACT, bool TX = false>
+template <int EPI, int ACT>
 static hipError_t launch_conv_pp16_e(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = 160 * 1024;     // main loop 151,680 B (+ 10,240 B scale/shift table with TX); the epilogue stages the whole tile
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp16_kernel<EPI, ACT, TX>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const size_t lds = 160 * 1024;     // main loop 151,680 B; the epilogue stages the whole tile
+    static DeviceOnce once;
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp16_kernel<EPI, ACT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     dim3 grid(a.Mrows / 256, a.Npad / 320);
-    hipLaunchKernelGGL((conv_pp16_kernel<EPI, ACT, TX>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_pp16_kernel<EPI, ACT>), grid, dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -303,7 +253,6 @@ hipError_t launch_conv_pp16(const GemmArgs& a, hipStream_t st) {
     if (a.mul != nullptr || a.out_f32 != 0) return hipErrorInvalidValue;      // 3x3 convs never use these
     if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
     if (a.res != nullptr) {                     // conv2 of a block with the block's tail fused (conv_tail16.h)
-        if (a.tx_table != nullptr || (a.out_gn != nullptr && (a.y2 != nullptr || a.gn_gamma == nullptr))) return hipErrorInvalidValue;
         if (a.N != 320 || a.Npad != 320 || a.ldo != 320 || a.bias != nullptr || a.out_stats != nullptr) return hipErrorInvalidValue;
         if (a.y2 != nullptr && a.gn_gamma == nullptr) return hipErrorInvalidValue;
         if (a.se_w1 != nullptr && (a.se_hidden < 8 || a.se_hidden > 128 || a.se_hidden % 8 != 0 || a.se_w1h == nullptr ||
@@ -319,16 +268,9 @@ hipError_t launch_conv_pp16(const GemmArgs& a, hipStream_t st) {
         return hipErrorInvalidValue;
     }
     if (a.gn_gamma != nullptr) {                // conv1 of a block: GroupNorm + the network activation
-        if (a.tx_table != nullptr) {            // ... reading the raw residual stream (GroupNorm-on-load)
-            if (a.Cin != 320 || a.Npad != 320) return hipErrorInvalidValue;
-            if (a.epi_act == ACT_SILU) return launch_conv_pp16_e<1, ACT_SILU, true>(a, st);
-            if (a.epi_act == ACT_RELU) return launch_conv_pp16_e<1, ACT_RELU, true>(a, st);
-            return hipErrorInvalidValue;
-        }
         if (a.epi_act == ACT_SILU) return launch_conv_pp16_e<1, ACT_SILU>(a, st);
         if (a.epi_act == ACT_RELU) return launch_conv_pp16_e<1, ACT_RELU>(a, st);
         return hipErrorInvalidValue;
     }
-    if (a.tx_table != nullptr) return hipErrorInvalidValue;
     return a.epi_act == ACT_NONE ? launch_conv_pp16_e<0, ACT_NONE>(a, st) : hipErrorInvalidValue;
 }

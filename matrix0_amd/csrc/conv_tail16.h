@@ -60,7 +60,7 @@ __device__ __forceinline__ void conv_tail_epilogue16(float4v (&acc)[4][10], cons
     const int chunk = lane % NCH, rsub = lane / NCH;
     const bool lane_on = rsub < 3;
     float gg[8], bb[8];
-    if (a.y2 != nullptr || a.out_gn != nullptr) {
+    if (a.y2 != nullptr) {
         const int c0 = wn * 160 + chunk * 8;
         const float4 g0 = *reinterpret_cast<const float4*>(a.gn_gamma + c0), g1 = *reinterpret_cast<const float4*>(a.gn_gamma + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(a.gn_beta + c0), b1 = *reinterpret_cast<const float4*>(a.gn_beta + c0 + 4);
@@ -238,7 +238,7 @@ __device__ __forceinline__ void conv_tail_epilogue16(float4v (&acc)[4][10], cons
 #ifdef TAIL_NO_Y2
     return;
 #endif
-    if (a.y2 == nullptr && a.out_gn == nullptr) return;
+    if (a.y2 == nullptr) return;
 
     // GroupNorm statistics of y: over the 3 row classes (lanes chunk, chunk+20, chunk+40), then over the group's 16
     // channels = this lane's 8 + the neighbour chunk's 8
@@ -261,16 +261,6 @@ __device__ __forceinline__ void conv_tail_epilogue16(float4v (&acc)[4][10], cons
         constexpr int i = decltype(i_)::value;
         scl[i] = gg[i] * rstd; shl[i] = bb[i] - mean * scl[i];
     });
-    if (a.y2 == nullptr) {
-        // GroupNorm-on-load consumer (net_kernels.h): only (scale, shift) per (board, channel) leave the kernel
-        if (rsub == 0) {
-            float4* o = reinterpret_cast<float4*>(a.out_gn + ((size_t)(m0 / 64 + wm) * 320 + wn * 160 + chunk * 8) * 2);
-            o[0] = make_float4(scl[0], shl[0], scl[1], shl[1]); o[1] = make_float4(scl[2], shl[2], scl[3], shl[3]);
-            o[2] = make_float4(scl[4], shl[4], scl[5], shl[5]); o[3] = make_float4(scl[6], shl[6], scl[7], shl[7]);
-        }
-        TAIL_STAMP(4);
-        return;
-    }
     // E: y2 = act(GroupNorm(y)) from the image
     char* y2out = reinterpret_cast<char*>(a.y2) + tile_off;
 #pragma unroll

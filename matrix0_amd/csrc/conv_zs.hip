@@ -1,6 +1,6 @@
 // conv_zs_kernel: the 3x3 320->320 implicit-GEMM conv of the tower with the zero padding SKIPPED.
 //
-// conv_pp16_kernel (read its header and conv_pp.hip's: same workgroup tile of 4 boards x 320 channels, LDS images, DMA ring,
+// conv_pp16_kernel (read its header and tools/ubench/conv_pp.hip's: same workgroup tile of 4 boards x 320 channels, LDS images, DMA ring,
 // ping-pong groups and barrier protocol) gives a wave one board x 160 channels, M-tile = 16 consecutive squares.  A 3x3 conv
 // on an 8x8 board multiplies 92 of its 576 (square, tap) pairs by the zero padding; the main loop is POWER-bound (DESIGN.md
 // section 5), so those MFMAs cost wall time.  Here a wave owns TWO boards x 80 channels and M-tile mi = board row y = mi of
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     if (wp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
-    // ---- steady-state DMA (wave-uniform state, advanced incrementally; see conv_pp.hip) ----
+    // ---- steady-state DMA (wave-uniform state, advanced incrementally; see tools/ubench/conv_pp.hip) ----
     const uint32_t w_lane = (uint32_t)lane * 16u;
     // activation piece qq = 4 xi + wave - 4 (xi = 0..7): rows 32 xi + 8 (wave - 4) + (lane >> 3); key = (lane >> 4) | (xi & 2) << 1
     const uint32_t a_lane0 = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + 16u * (uint32_t)((lane & 7) ^ (lane >> 4));
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's tail refetches / fillers have landed
     if (wp == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
-    __builtin_amdgcn_s_barrier();                       // every wave's DMA has landed before anyone stages output (conv_pp.hip)
+    __builtin_amdgcn_s_barrier();                       // every wave's DMA has landed before anyone stages output (tools/ubench/conv_pp.hip)
 
 #ifdef PP_NO_EPILOGUE
 #pragma unroll
@@ -236,13 +236,12 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
 template <int EPI, int ACT>
 static hipError_t launch_conv_zs_e(const GemmArgs& a, hipStream_t st) {
     const size_t lds = 160 * 1024;     // main loop 159,744 B; the epilogue stages the whole tile (8 x 20 KiB)
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_zs_kernel<EPI, ACT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DeviceOnce once;             // the attribute is per device: a process may drive several GPUs (arena, tests)
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_zs_kernel<EPI, ACT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     dim3 grid(a.Mrows / 256, a.Npad / 320);
     hipLaunchKernelGGL((conv_zs_kernel<EPI, ACT>), grid, dim3(512), lds, st, a);
     return hipGetLastError();
@@ -250,7 +249,6 @@ static hipError_t launch_conv_zs_e(const GemmArgs& a, hipStream_t st) {
 
 // true: launch_conv_zs takes these arguments (the dispatcher falls back to conv_pp16_kernel otherwise)
 bool conv_zs_supports(const GemmArgs& a) {
-    if (a.tx_table != nullptr || a.out_gn != nullptr) return false;                 // GroupNorm-on-load experiment: conv_pp16 only
     if (a.res != nullptr && a.se_w1 != nullptr && (a.se_wf == nullptr || a.se_hidden > ZS_SE_HMAX)) return false;   // fragment-order weights
     return true;
 }

@@ -9,6 +9,22 @@
 #include <type_traits>
 #include <utility>
 
+// Host side: run `f` once per HIP device (hipFuncSetAttribute is per device; a process may hold networks on several GPUs,
+// and SelfplayPool threads launch concurrently).  f returns hipError_t; a failure is retried on the next call.
+#include <atomic>
+struct DeviceOnce {
+    std::atomic<uint32_t> done{0};          // bit d = device d configured (devices >= 32 run f every time)
+    template <typename F>
+    hipError_t run(F&& f) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return hipErrorInvalidDevice;
+        if ((unsigned)d < 32u && (done.load(std::memory_order_acquire) >> d) & 1u) return hipSuccess;
+        const hipError_t e = f();
+        if (e == hipSuccess && (unsigned)d < 32u) done.fetch_or(1u << d, std::memory_order_release);
+        return e;
+    }
+};
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 

@@ -20,7 +20,7 @@ struct PackedGemm {
     _Float16* w = nullptr;   // [taps][Cin/KC][N][KC]
     float* bias = nullptr;   // [N] or null
     int taps = 1, Cin = 0, N = 0;
-    bool pp = false;         // 3x3 big tile in conv_pp_kernel's layout [chunk*9+tap][N/320][k half][320][32]
+    bool pp = false;         // 3x3 big tile in the half-tile layout of conv_zs_kernel / conv_pp16_kernel [chunk*9+tap][N/320][k half][320][32]
 };
 
 struct NormParams {
@@ -61,7 +61,8 @@ struct SslHeadW {
 
 class Net {
 public:
-    explicit Net(const m0_net_cfg& cfg, int device);
+    // `stream`: the HIP stream every forward of this network runs on (allocations are cleared on it)
+    explicit Net(const m0_net_cfg& cfg, int device, hipStream_t stream);
     ~Net();
     static const char* check_supported(const m0_net_cfg& cfg);
     int load(const char* name, const void* data, int dtype, const int64_t* shape, int ndim, std::string& err);
@@ -93,6 +94,8 @@ public:
 private:
     m0_net_cfg cfg_;
     int device_;
+    hipStream_t stream_ = nullptr;
+    struct Switches { bool fuse_tail = true, fuse_attn = true, splitk = true, conv_zs = true; } sw_;   // read once (constructor)
     bool finalized_ = false;
     size_t nparams_ = 0;
     std::map<std::string, HostTensor> sd_;
@@ -129,7 +132,6 @@ private:
     int wsB_ = 0, wsM_ = 0;
     _Float16 *X0_ = nullptr, *XA_ = nullptr, *XB_ = nullptr, *T1_ = nullptr, *T2_ = nullptr, *QKV_ = nullptr,
              *O_ = nullptr, *AA_ = nullptr;
-    const NormParams* tx_next_ = nullptr;   // set by forward() right before a conv1 launch that reads the raw stream (run_gemm)
     float *SX_ = nullptr, *S1_ = nullptr, *S2_ = nullptr, *G_ = nullptr;   // G_: squeeze-excite gates [B][C]
     _Float16 *PH_ = nullptr, *PH2_ = nullptr, *VH_ = nullptr, *VH2_ = nullptr, *F1_ = nullptr, *F2_ = nullptr,
              *F3_ = nullptr, *F4_ = nullptr, *SH_ = nullptr, *SH2_ = nullptr, *SO_ = nullptr;

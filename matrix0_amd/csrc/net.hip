@@ -34,7 +34,13 @@ const char* Net::check_supported(const m0_net_cfg& c) {
     return nullptr;
 }
 
-Net::Net(const m0_net_cfg& cfg, int device) : cfg_(cfg), device_(device) {
+Net::Net(const m0_net_cfg& cfg, int device, hipStream_t stream) : cfg_(cfg), device_(device), stream_(stream) {
+    // kernel-variant switches (A/B runs): read ONCE, here, so that the layout decisions of forward() and the dispatcher agree
+    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+    sw_.fuse_tail = !off("M0_FUSE_TAIL");     // =0: conv2 + se_gate + ew_board as separate kernels
+    sw_.fuse_attn = !off("M0_FUSE_ATTN");     // =0: qkv GEMM + attn_core + proj GEMM + ew_board as separate kernels
+    sw_.splitk = !off("M0_SPLITK");           // =0: value_fc1 never splits K
+    sw_.conv_zs = !off("M0_CONV_ZS");         // =0: conv_pp16_kernel instead of conv_zs_kernel
     C_ = cfg.channels;
     Cp_ = (C_ > 256 && C_ < 320) ? 320 : C_;
     Cs_ = ceil_to(std::max(16, C_ / 2), 32);
@@ -63,7 +69,10 @@ void* Net::dalloc(size_t bytes, bool ws) {
     void* p = nullptr;
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, bytes);
+    // cleared ON THE STREAM THAT WILL USE IT (a NULL-stream hipMemset is not ordered with the non-blocking streams: round 2's
+    // regrowth race).  Weight buffers are filled next by blocking NULL-stream copies, so their clear is waited for here.
+    (void)hipMemsetAsync(p, 0, bytes, stream_);
+    if (!ws) (void)hipStreamSynchronize(stream_);
     (ws ? ws_allocs_ : dev_allocs_).push_back(p);
     return p;
 }
@@ -108,7 +117,7 @@ int Net::pack_gemm(PackedGemm& g, const std::string& wkey, const std::string& bk
     nparams_ += expect;
     const int KC = conv_gemm_kc(Cin_pad, N_pad);
     const int nchunk = Cin_pad / KC;
-    const bool pp = KC == 64 && taps == 9;       // 3x3 big tile: conv_pp_kernel's half-tile layout
+    const bool pp = KC == 64 && taps == 9;       // 3x3 big tile: the half-tile layout of conv_zs_kernel / conv_pp16_kernel
     const int nblk = N_pad / 320;
     std::vector<_Float16> p((size_t)taps * Cin_pad * N_pad, (_Float16)0.f);
     for (int nr = 0; nr < N_real; ++nr)
@@ -405,7 +414,7 @@ int Net::finalize(std::string& err) {
         }
     }
     sd_.clear();
-    (void)hipDeviceSynchronize();       // uploads and clears (NULL stream) have landed before any non-blocking stream reads them
+    (void)hipDeviceSynchronize();       // uploads (blocking NULL-stream copies) have landed before any non-blocking stream reads them
     finalized_ = true;
     return M0_OK;
 }
@@ -470,9 +479,9 @@ int Net::ensure_workspace(int B, std::string& err) {
         wsB_ = wsM_ = 0;
         return M0_ERR_HIP;
     }
-    // dalloc clears with hipMemset on the NULL stream; the forward runs on a non-blocking stream that does not wait for it -- without
-    // this the clears of a regrown workspace (GBs at self-play batch sizes) race with the first kernels that write it
-    if (hipDeviceSynchronize() != hipSuccess) { err = "workspace clear failed"; wsB_ = wsM_ = 0; return M0_ERR_HIP; }
+    // the clears were enqueued on stream_, the stream every forward of this network runs on: ordered before the first kernel
+    // (tests/test_net_gpu.py::test_workspace_regrowth_keeps_results)
+    if (hipGetLastError() != hipSuccess) { err = "workspace clear failed"; wsB_ = wsM_ = 0; return M0_ERR_HIP; }
     wsB_ = Bp; wsM_ = Mfc;
     return M0_OK;
 }
@@ -488,10 +497,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     a.bias = g.bias; a.mul = mul; a.out_stats = out_stats;
     a.Mrows = Mrows; a.Mvalid = Mvalid; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
     a.epi_act = epi_act; a.out_f32 = out_f32 ? 1 : 0; a.out_scale = out_scale; a.w_pp = g.pp ? 1 : 0;
-    if (tx_next_) {                   // GroupNorm-on-load: `in` is the raw residual stream (set by forward() for this launch only)
-        a.tx_table = SX_;
-        tx_next_ = nullptr;
-    }
+    a.no_zs = sw_.conv_zs ? 0 : 1;
     const bool timed = profile_ && g.taps == 9 && conv_gemm_tile_n(g.Cin, g.N) == 320;
     if (timed) {
         if (pev_used_ + 2 > pev_.size()) {
@@ -504,8 +510,7 @@ hipError_t Net::run_gemm(const PackedGemm& g, const _Float16* in, void* out, int
     // tiles, then a fixed-order reduction with the bias and the activation.  Taken at EVERY batch size: the summation order of a
     // board's value must not depend on how many other boards share the launch (tests/test_net_gpu.py: bitwise batch invariance up
     // to the 24 832 boards of a self-play pass); at large batches the partial tiles cost ~0.1 % of the forward.
-    const char* skenv = getenv("M0_SPLITK");           // =0: never split (A/B runs)
-    const bool splitk = !(skenv && skenv[0] == '0') && g.taps == 1 && conv_gemm_tile_n(g.Cin, g.N) == 320 && g.Cin >= 4096 &&
+    const bool splitk = sw_.splitk && g.taps == 1 && conv_gemm_tile_n(g.Cin, g.N) == 320 && g.Cin >= 4096 &&
                         (g.Cin >> 6) % 8 == 0 && !out_norm && !mul && !out_stats && !out_f32 && out_scale == 1.f && SPK_ != nullptr &&
                         (size_t)g.N <= (size_t)ceil_to(2 * C_, 32) && Mrows <= wsM_;
     if (splitk) {
@@ -531,10 +536,9 @@ hipError_t Net::run_conv_tail(const ResBlockW& r, const _Float16* in, const _Flo
     memset(&a, 0, sizeof(a));
     a.in = in; a.w = g.w; a.out = y;
     a.Mrows = Mrows; a.Mvalid = Mrows; a.Cin = g.Cin; a.N = g.N; a.Npad = g.N; a.ldo = g.N;
-    a.epi_act = act; a.out_scale = 1.f; a.w_pp = g.pp ? 1 : 0;
+    a.epi_act = act; a.out_scale = 1.f; a.w_pp = g.pp ? 1 : 0; a.no_zs = sw_.conv_zs ? 0 : 1;
     a.res = x;
     if (next_bn1 && y2) { a.y2 = y2; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }
-    else if (next_bn1 && !y2) { a.out_gn = SX_; a.gn_gamma = next_bn1->gamma; a.gn_beta = next_bn1->beta; }   // GroupNorm-on-load
     if (cfg_.se) { a.se_w1 = r.se_w1; a.se_b1 = r.se_b1; a.se_w2 = r.se_w2; a.se_b2 = r.se_b2; a.se_hidden = r.se_hidden;
                    a.se_w1h = r.se_w1h; a.se_w2h = r.se_w2h; a.se_wf = r.se_wf; }
     const bool timed = profile_;
@@ -595,19 +599,9 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         x0 = X0_;
     }
     const bool big = conv_gemm_tile_n(C, C) == 320;     // fused GN epilogue available (C % 320 == 0)
-    const char* ftenv = getenv("M0_FUSE_TAIL");          // =0: conv2 + se_gate + ew_board as separate kernels
-    const bool fuse_tail = big && C == 320 && !(ftenv && ftenv[0] == '0') &&
+    const bool fuse_tail = big && C == 320 && sw_.fuse_tail &&
                            (!cfg_.se || (res_[0].se_hidden >= 4 && res_[0].se_hidden <= 128 && res_[0].se_hidden % 4 == 0));
-    const char* faenv = getenv("M0_FUSE_ATTN");          // =0: qkv GEMM + attn_core + proj GEMM + ew_board as separate kernels
-    const bool fuse_attn = C == 320 && !(faenv && faenv[0] == '0');
-    // GroupNorm-on-load (M0_CONV_TX=1, off by default): the tail / attention kernels store the raw residual stream y plus a
-    // (scale, shift) table per (board, channel) and conv1 of the next block normalises + activates its activation tiles in LDS --
-    // the pre-activated copy y2 (84 MB per block at 4096 boards) is never written.  Measured: the tail gets 31 us shorter, conv1
-    // 45 us longer (conv_pp16.hip), so the y2 path stays the default.
-    const char* txenv = getenv("M0_CONV_TX");
-    const char* m32env = getenv("M0_CONV_MFMA32");
-    const bool tx_on = fuse_tail && fuse_attn && C == 320 && (txenv && txenv[0] == '1') && !(m32env && m32env[0] == '1');
-    bool stats_ready = false;          // SX_ holds the statistics of the current stream xa
+    const bool fuse_attn = C == 320 && sw_.fuse_attn;
     // ew: elementwise glue; y2/gn2 = pre-activated input of the NEXT residual block (its bn1), or null
     auto ew = [&](const _Float16* t, const float* tst, const NormParams* gn, const ResBlockW* se, const _Float16* res,
                   const float* pos, const NormParams* ln, _Float16* y, float* ost, const NormParams* next_bn1,
@@ -673,10 +667,9 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             memset(&ia, 0, sizeof(ia));
             ia.in = xa; ia.w = inter_.w; ia.out = xb;
             ia.Mrows = Mc; ia.Mvalid = Mc; ia.Cin = inter_.Cin; ia.N = inter_.N; ia.Npad = inter_.N; ia.ldo = inter_.N;
-            ia.epi_act = act; ia.out_scale = 1.f; ia.w_pp = inter_.pp ? 1 : 0;
+            ia.epi_act = act; ia.out_scale = 1.f; ia.w_pp = inter_.pp ? 1 : 0; ia.no_zs = sw_.conv_zs ? 0 : 1;
             ia.res = xa; ia.pre_gamma = inter_n_.gamma; ia.pre_beta = inter_n_.beta;
-            if (first_bn1 && tx_on) { ia.out_gn = SX_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; stats_ready = true; }
-            else if (first_bn1) { ia.y2 = AA_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; }
+            if (first_bn1) { ia.y2 = AA_; ia.gn_gamma = first_bn1->gamma; ia.gn_beta = first_bn1->beta; }
             KCHK(launch_conv_gemm(ia, 9, st));
         } else {
             KCHK(run_gemm(inter_, xa, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
@@ -694,16 +687,14 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             // pre-activation block (resnet.py:45-51): AA_ = act(GN1(x)) comes from the previous ew; conv1's
             // epilogue applies GN2+act in registers (big tile) so conv2 also reads a ready operand
             if (big) {
-                if (tx_on && stats_ready) tx_next_ = &r.bn1;          // conv1 reads the raw stream and applies bn1 + act itself
-                KCHK(run_gemm(r.conv1, (tx_on && stats_ready) ? xa : AA_, T1_, Mc, Mc, &r.bn2, act, nullptr, nullptr, false, 1.f, st));
+                KCHK(run_gemm(r.conv1, AA_, T1_, Mc, Mc, &r.bn2, act, nullptr, nullptr, false, 1.f, st));
             } else {
                 KCHK(run_gemm(r.conv1, AA_, T2_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
                 KCHK(ew(T2_, S1_, &r.bn2, nullptr, nullptr, nullptr, nullptr, T1_, nullptr, nullptr, nullptr, C, Bp));
             }
             if (fuse_tail) {
                 // conv2 + squeeze-excite + residual add + the next block's GroupNorm/activation in one kernel
-                KCHK(run_conv_tail(r, T1_, xa, xb, next_bn1_after(li), tx_on ? nullptr : AA_, act, Mc, st));
-                stats_ready = tx_on && next_bn1_after(li) != nullptr;
+                KCHK(run_conv_tail(r, T1_, xa, xb, next_bn1_after(li), AA_, act, Mc, st));
             } else {
                 KCHK(run_gemm(r.conv2, T1_, T2_, Mc, Mc, nullptr, 0, nullptr, S2_, false, 1.f, st));
                 KCHK(ew(T2_, S2_, nullptr, cfg_.se ? &r : nullptr, xa, nullptr, nullptr, xb, nullptr, next_bn1_after(li), AA_, C, Bp));
@@ -719,8 +710,7 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
                 ab.x = xa; ab.wpack = w.blk_w; ab.bias = w.blk_bias; ab.mask = mask_dev_;
                 ab.ln_g = w.ln.gamma; ab.ln_b = w.ln.beta; ab.y = xb;
                 if (const NormParams* nb = next_bn1_after(li)) {
-                    if (tx_on) { ab.out_gn = SX_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; stats_ready = true; }
-                    else { ab.y2 = AA_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta; }
+                    ab.y2 = AA_; ab.gn2_gamma = nb->gamma; ab.gn2_beta = nb->beta;
                 }
                 ab.B = Bp; ab.ln_count = C_; ab.act = act; ab.mix = cfg_.attention_unmasked_mix;
                 ab.inv_sqrt_d = 1.f / sqrtf((float)(C_ / cfg_.attention_heads));

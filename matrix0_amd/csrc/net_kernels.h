@@ -25,7 +25,7 @@ struct GemmArgs {
     float out_scale;
     int ksplit;              // conv_big_kernel<1>: > 1 = split K over gridDim.y, workgroup z writes its fp32 partial tile to
                              // out + z * Mrows * ldo floats (out_f32 = 1, no bias / act); reduced by launch_splitk_reduce
-    int w_pp;                // 3x3 big tile: w is in conv_pp_kernel's half-tile layout (pack_gemm)
+    int w_pp;                // 3x3 big tile: w is in the half-tile layout of conv_zs_kernel / conv_pp16_kernel (pack_gemm)
     // residual-block tail fused into the epilogue (conv_tail.h), when res != null: out = res + gate * conv,
     // y2 = epi_act(GroupNorm16(out; gn_gamma, gn_beta)) when y2 != null, gate from se_* when se_w1 != null
     const _Float16* res;     // [Mrows][ldo]
@@ -37,15 +37,9 @@ struct GemmArgs {
     const float* se_w2;      // [Hd][C] (transposed)
     const float* se_b2;
     int se_hidden;
-    // GroupNorm-on-load (conv_pp16_kernel, conv1 of a residual block): the producer of `in` stored the RAW residual stream y
-    // and, per (board, channel), the (scale, shift) of the next block's GroupNorm16 -- scale = rstd * gamma, shift = beta -
-    // mean * scale -- in out_gn [Mrows/64][320][2]; the consumer brings its 4 boards' table into LDS with the prologue DMA and
-    // applies act(y * scale + shift) to the activation tiles in LDS right after they land: the pre-activated copy y2 of the
-    // stream (84 MB per block at 4096 boards) is never written to HBM.
-    float* out_gn;           // producer (tail epilogues): the table instead of y2 (y2 null; gn_gamma / gn_beta = the NEXT bn1)
-    const float* tx_table;   // consumer: [Mrows/64][320][2] for `in`; null = `in` is already activated
     const _Float16* se_w1h;  // fp16 copies of se_w1 / se_w2 (same layouts): conv_pp16's tail stages BOTH in LDS with one DMA
     const _Float16* se_w2h;  //   wave (half the bytes of the f32 matrices, which it brought in one after the other)
+    int no_zs;               // 3x3 big tile: 1 = conv_pp16_kernel instead of conv_zs_kernel (M0_CONV_ZS=0, read once per network)
     const void* se_wf;       // conv_zs_kernel's tail: W1 and W2 as fp16 MFMA B-fragment pieces of 1 KiB (conv_zs_tail.h; net.hip packs)
 };
 
@@ -102,7 +96,6 @@ struct AttnBlockArgs {
     const float* gn2_beta;
     _Float16* y;             // [B][64][320] LayerNorm(x + attention(x))
     _Float16* y2;            // [B][64][320] or null
-    float* out_gn;           // with y2 == null: [B][320][2] (scale, shift) of GroupNorm16(y; gn2_*) per channel (GroupNorm-on-load)
     int B;                   // boards, even
     int ln_count;            // real channel count of the LayerNorm
     int act;                 // ACT_SILU / ACT_RELU (y2)

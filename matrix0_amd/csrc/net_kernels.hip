@@ -216,20 +216,18 @@ template <int TAPS, int WN, int NT, int KC>
 static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
     constexpr int NB = WN * NT * 32;
     size_t lds = conv_gemm_lds<TAPS, WN, NT, KC>(a.Cin);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<TAPS, WN, NT, KC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<TAPS, WN, NT, KC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     dim3 grid(a.Mrows / 256, a.Npad / NB);
     hipLaunchKernelGGL((conv_gemm_kernel<TAPS, WN, NT, KC>), grid, dim3(256 * WN), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
-hipError_t launch_conv_pp(const GemmArgs& a, hipStream_t st);              // conv_pp.hip
 hipError_t launch_conv_pp16(const GemmArgs& a, hipStream_t st);            // conv_pp16.hip
 hipError_t launch_conv_zs(const GemmArgs& a, hipStream_t st);              // conv_zs.hip
 bool conv_zs_supports(const GemmArgs& a);
@@ -248,13 +246,11 @@ hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     if (taps == 9) {
         if (big) {
             if (!a.w_pp) return hipErrorInvalidValue;
-            // v_mfma_f32_16x16x32_f16 main loop (conv_pp16.hip) unless M0_CONV_MFMA32=1 asks for the 32x32x16 one (A/B runs)
-            static const bool mfma32 = [] { const char* e = getenv("M0_CONV_MFMA32"); return e && e[0] == '1'; }();
-            if (mfma32) return launch_conv_pp(a, st);
-            // conv_zs_kernel: the same loop with the wave tile laid out so that the M-tiles that only see the zero padding above /
-            // below the board are skipped (8.3 % of the MFMAs); M0_CONV_ZS=0 keeps conv_pp16_kernel (A/B runs)
-            const char* zs = getenv("M0_CONV_ZS");
-            if (!(zs && zs[0] == '0') && conv_zs_supports(a)) return launch_conv_zs(a, st);
+            // conv_zs_kernel: the v_mfma_f32_16x16x32_f16 loop with the wave tile laid out so that the M-tiles that only see the
+            // zero padding above / below the board are skipped (8.3 % of the MFMAs).  conv_pp16_kernel (the same loop without the
+            // skipping) takes the shapes conv_zs does not (squeeze-excite wider than 96 hidden units) and A/B runs
+            // (GemmArgs::no_zs, set from M0_CONV_ZS=0 when the network is created).
+            if (!a.no_zs && conv_zs_supports(a)) return launch_conv_zs(a, st);
             return launch_conv_pp16(a, st);
         }
         return launch_conv_gemm_t<9, 1, 1, 32>(a, st);

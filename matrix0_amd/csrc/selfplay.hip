@@ -106,7 +106,7 @@ T* dalloc(m0_selfplay* sp, size_t count) {
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, bytes);
+    (void)hipMemsetAsync(p, 0, bytes, sp->stream);          // on the engine's own stream: ordered before every kernel that uses it
     sp->allocs.push_back(p);
     return (T*)p;
 }
@@ -256,7 +256,13 @@ void finish_game(m0_selfplay* sp, int slot, bool resigned, int resigner, bool ha
         if (c.ssl_targets && (int)hgm.rec_pos.size() == hgm.nstates) {
             // targets for all plies of the game in one launch on the engine stream
             const int T = hgm.nstates;
-            if (T <= sp->ssl_cap && sp->ssl_pos_dev && sp->ssl_out_dev) {      // buffers allocated once per engine
+            if (T > sp->ssl_cap) {             // a game longer than the staging buffers (max_game_len <= 0): grow them
+                Pos* np = dalloc<Pos>(sp, (size_t)T + 64);
+                float* no = dalloc<float>(sp, ((size_t)T + 64) * 17 * 64);
+                if (np && no) { sp->ssl_pos_dev = np; sp->ssl_out_dev = no; sp->ssl_cap = T + 64; }   // the old pair is freed with the engine
+                else sp->stats.ssl_dropped++;
+            }
+            if (T <= sp->ssl_cap) {
                 o->ssl.resize((size_t)T * 17 * 64);
                 (void)hipMemcpyAsync(sp->ssl_pos_dev, hgm.rec_pos.data(), sizeof(Pos) * T, hipMemcpyHostToDevice, sp->stream);
                 (void)launch_ssl_targets(sp->ssl_pos_dev, T, sp->ssl_out_dev, sp->stream);
@@ -571,6 +577,11 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
         sp->ssl_cap = cfg->max_game_len > 0 ? cfg->max_game_len + 1 : 513;
         sp->ssl_pos_dev = dalloc<Pos>(sp, sp->ssl_cap);
         sp->ssl_out_dev = dalloc<float>(sp, (size_t)sp->ssl_cap * 17 * 64);
+        if (!sp->ssl_pos_dev || !sp->ssl_out_dev) {
+            m0_set_error("hipMalloc failed for the SSL target staging buffers");
+            m0_selfplay_destroy(sp);
+            return nullptr;
+        }
     }
     sp->ids_dev = dalloc<int>(sp, sp->G);
     sp->slots_dev = dalloc<int>(sp, sp->G);
@@ -596,9 +607,12 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
         if (sp->net->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
         if (sp->net_b && sp->net_b->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
     }
-    // the allocations above were cleared with hipMemset on the NULL stream, which the engine's non-blocking stream does not wait
-    // for: everything must have landed before the first kernel touches the arenas
-    (void)hipDeviceSynchronize();
+    // the clears ride the engine's stream; wait once so that an allocation / clear failure surfaces here, not in the first step
+    if (hipStreamSynchronize(sp->stream) != hipSuccess) {
+        m0_set_error(std::string("clearing the search arenas failed: ") + hipGetErrorString(hipGetLastError()));
+        m0_selfplay_destroy(sp);
+        return nullptr;
+    }
     return sp;
 }
 

@@ -37,7 +37,7 @@ class SelfplayCfg(C.Structure):
 class SelfplayStats(C.Structure):
     _fields_ = [("steps", c_u64), ("evals", c_u64), ("sims", c_u64), ("plies", c_u64), ("games_finished", c_u64),
                 ("games_started", c_u64), ("ms_total", c_double), ("ms_net", c_double), ("ms_tree", c_double),
-                ("ms_host", c_double), ("arena_overflows", c_u64), ("active_games", c_int)]
+                ("ms_host", c_double), ("arena_overflows", c_u64), ("ssl_dropped", c_u64), ("active_games", c_int)]
 
 
 class GameRecord(C.Structure):

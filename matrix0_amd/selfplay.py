@@ -129,6 +129,7 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     last_hb = time.perf_counter()
     done = 0
     overflows = 0
+    ssl_dropped = 0
     try:
         while engine.running():
             engine.step(int(eng_cfg.get("steps_per_poll", 8)))
@@ -167,6 +168,10 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
                 overflows = int(st["arena_overflows"])
                 logger.warning("worker %d: %d searches hit the node-arena limit or ended without visits; raise engine.arena_nodes",
                                proc_id, overflows)
+            if int(st.get("ssl_dropped", 0)) > ssl_dropped:
+                ssl_dropped = int(st["ssl_dropped"])
+                logger.warning("worker %d: %d games were written without ssl_* targets (staging buffers could not grow)",
+                               proc_id, ssl_dropped)
             if q is not None and now - last_hb >= 2.0:             # internal.py:542-556
                 q.put({"type": "heartbeat", "proc": proc_id, "game": done, "moves": int(st["plies"]),
                        "avg_sims": float(st["sims"]) / max(1.0, float(st["plies"])), "resigned": False,

@@ -123,8 +123,10 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
         x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
         x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
         monkeypatch.setenv("M0_FUSE_TAIL", "0")
-        p_split, v_split = be.infer_np(x.numpy())
-        monkeypatch.setenv("M0_FUSE_TAIL", "1")
+        be_split = M0Backend.from_state_dict(cfg, sd)         # the kernel switches are read once, when a network is created
+        monkeypatch.delenv("M0_FUSE_TAIL")
+        p_split, v_split = be_split.infer_np(x.numpy())
+        be_split.close()
         p_fused, v_fused = be.infer_np(x.numpy())
         assert np.abs(p_fused - p_split).max() <= 2e-3
         assert np.abs(v_fused - v_split).max() <= 2e-3
@@ -134,9 +136,9 @@ def test_fused_block_tail_matches_split_kernels(monkeypatch):
 
 
 def test_conv_kernel_variants_agree(monkeypatch):
-    """The three 3x3 conv kernels compute the same convolution: conv_zs_kernel (default: the MFMA tiles that only multiply zero
-    padding are not issued, squeeze-excite FCs on the matrix cores), conv_pp16_kernel (M0_CONV_ZS=0) and conv_pp_kernel
-    (M0_CONV_ZS=0 M0_CONV_MFMA32=1 is read once per process, so only the first two are switched here).  Variants: silu + SE
+    """The two 3x3 conv kernels of the library compute the same convolution: conv_zs_kernel (default: the MFMA tiles that only
+    multiply zero padding are not issued, squeeze-excite FCs on the matrix cores) and conv_pp16_kernel (M0_CONV_ZS=0 when the
+    network is created; also the fallback for squeeze-excite layers wider than 96 hidden units).  Variants: silu + SE
     (80 hidden units), relu + SE, a small SE ratio (hidden = 8: one FC1 tile, one FC2 k-step), and a ragged batch."""
     from matrix0_amd.backend import M0Backend
     for extra in ({}, {"activation": "relu"}, {"se_ratio": 0.025}):
@@ -149,9 +151,12 @@ def test_conv_kernel_variants_agree(monkeypatch):
         x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
         x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
         x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+        # the kernel switches are read once, when a network is created: one backend per variant
         monkeypatch.setenv("M0_CONV_ZS", "0")
-        p16, v16 = be.infer_np(x.numpy())
-        monkeypatch.setenv("M0_CONV_ZS", "1")
+        be16 = M0Backend.from_state_dict(cfg, sd)
+        monkeypatch.delenv("M0_CONV_ZS")
+        p16, v16 = be16.infer_np(x.numpy())
+        be16.close()
         pzs, vzs = be.infer_np(x.numpy())
         assert np.abs(pzs - p16).max() <= 2e-3, extra
         assert np.abs(vzs - v16).max() <= 2e-3, extra
@@ -184,8 +189,10 @@ def test_fused_attention_block_matches_split_kernels(monkeypatch):
         x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
         x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
         monkeypatch.setenv("M0_FUSE_ATTN", "0")
-        p_split, v_split = be.infer_np(x.numpy())
-        monkeypatch.setenv("M0_FUSE_ATTN", "1")
+        be_split = M0Backend.from_state_dict(cfg, sd)         # switches are read once, at creation
+        monkeypatch.delenv("M0_FUSE_ATTN")
+        p_split, v_split = be_split.infer_np(x.numpy())
+        be_split.close()
         p_fused, v_fused = be.infer_np(x.numpy())
         assert np.abs(p_fused - p_split).max() <= 2e-3, extra
         assert np.abs(v_fused - v_split).max() <= 2e-3, extra
@@ -193,29 +200,6 @@ def test_fused_attention_block_matches_split_kernels(monkeypatch):
         for tag, p, v in (("split", p_split, v_split), ("fused", p_fused, v_fused)):
             _check(f"attn_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
         be.close()
-
-
-def test_groupnorm_on_load_variant_matches_default_path(monkeypatch):
-    """M0_CONV_TX=1: the tail / attention kernels emit a (scale, shift) table instead of the pre-activated copy of the stream
-    and conv1 normalises its activation tiles in LDS (conv_pp16.hip).  Both paths compute act(fp16(y) * scale + shift) in
-    fp32 from the same fp32 table, so the outputs normally agree to the bit; kept correct although it measured slower."""
-    from matrix0_amd.backend import M0Backend
-    cfg = dict(_r24_cfg(), blocks=6)
-    sd = net_ref.random_state_dict(cfg, seed=8)
-    be = M0Backend.from_state_dict(cfg, sd)
-    g = torch.Generator().manual_seed(14)
-    B = 22
-    x = torch.zeros(B, 19, 8, 8)
-    x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
-    x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
-    x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
-    monkeypatch.setenv("M0_CONV_TX", "0")
-    p0, v0 = be.infer_np(x.numpy())
-    monkeypatch.setenv("M0_CONV_TX", "1")
-    p1, v1 = be.infer_np(x.numpy())
-    assert np.abs(p1 - p0).max() <= 2e-3 and np.abs(v1 - v0).max() <= 2e-3
-    p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
-    _check("gn_on_load", p1, v1, p_ref.numpy(), v_ref.numpy())
 
 
 def test_shipped_config_288x22_zero_padded_trunk():

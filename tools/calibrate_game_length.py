@@ -38,6 +38,10 @@ out = {"games": len(recs), "games_requested": games, "complete": len(recs) == ga
        "decisive": int(sum(1 for r in recs if abs(r["result"]) == 1.0)),
        "evals": int(st["evals"]), "sims": int(st["sims"]), "plies": int(st["plies"]), "seconds": dt,
        "evals_per_ply": float(st["evals"] / max(1, st["plies"])),
+       # the generation lasts as long as its longest game: passes of the hot path per searched ply once the searches have
+       # drifted apart (in step it is ceil(sims / leaves) = 9 at 800 / 96)
+       "passes": int(st["steps"]), "passes_per_ply": float(st["steps"] / max(1.0, float(moves.max()))) if len(recs) else None,
+       "games_per_s_end_to_end": (len(recs) / dt) if len(recs) == games else None,
        "note": "searched plies per game (NPZ rows); opening_random_plies=12 not included; R24-320 random init, 800 sims/move, "
                f"{games} concurrent games, {leaves} leaves/tree/step"}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -15,9 +15,9 @@
 //      with vmcnt(6) at the end of L(y-1,1), i.e. before barrier 4y-2 (waves 0-3) / 4y-1 (waves 4-7).
 // WAR: the pieces of half-tile y+3 overwrite the slot of y-1 and are issued in L(y,1), after barrier 4y+1 (4y+2);
 //      the last reads of y-1 (waves 4-7, L(y-1,1)) are retired by the lgkmcnt wait of C(y-1,1), before barrier 4y.
-#include "kernel_common.h"
-#include "conv_epilogue.h"
-#include "conv_tail.h"
+#include "../../matrix0_amd/csrc/kernel_common.h"
+#include "../../matrix0_amd/csrc/conv_epilogue.h"
+#include "../../matrix0_amd/csrc/conv_tail.h"
 
 __device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_wave_base) {
     // LDS destination = wave-uniform base + lane*16 (hardware); the global source is per lane

@@ -3,10 +3,14 @@
 //         tools/ubench/conv_pp_bench.hip -o conv_pp_bench && ./conv_pp_bench [boards] [iters]
 // With -DPP_TRACE it prints, for waves 0 and 4 of one workgroup and 4 consecutive K-tiles, the cycle stamps
 // L-start / L-end(before barrier) / C-start(after barrier) / C-end(MFMAs issued) of each phase.
-#include "../../matrix0_amd/csrc/conv_pp.hip"
+#include "conv_pp.hip"
 #include "conv_sw.hip"
 #include "../../matrix0_amd/csrc/conv_pp16.hip"
 #include "../../matrix0_amd/csrc/conv_zs.hip"
+#include "conv_z2.hip"
+#ifdef BENCH_Z2
+#define launch_conv_pp launch_conv_z2
+#endif
 #ifdef BENCH_ZS
 #define launch_conv_pp launch_conv_zs
 #endif
@@ -98,6 +102,8 @@ int main(int argc, char** argv) {
     unsigned long long* dst_; hipMalloc(&dst_, (size_t)(M / 256) * 16 * 8); hipMemset(dst_, 0, (size_t)(M / 256) * 16 * 8);
 #if defined(BENCH_SW)
     hipMemcpyToSymbol(HIP_SYMBOL(g_sw_stamp), &dst_, sizeof(dst_));
+#elif defined(BENCH_Z2)
+    hipMemcpyToSymbol(HIP_SYMBOL(g_z2_stamp), &dst_, sizeof(dst_));
 #elif defined(BENCH_ZS)
     hipMemcpyToSymbol(HIP_SYMBOL(g_zs_stamp), &dst_, sizeof(dst_));
 #elif defined(BENCH_P16)
@@ -115,6 +121,26 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamp), &dtail_, sizeof(dtail_));
 #endif
     hipStream_t st; hipStreamCreate(&st);
+#ifdef BENCH_CMPZ2   // conv_z2_kernel (2 workgroups per CU) against conv_zs_kernel on the same operands: bit for bit
+    {
+        const size_t nb = (size_t)M * C * 2;
+        std::vector<_Float16> o1((size_t)M * C), o2((size_t)M * C);
+        hipMemset(dout, 0, nb);
+        hipError_t e1 = launch_conv_zs(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o1.data(), dout, nb, hipMemcpyDeviceToHost);
+        std::vector<float> s1, s2;
+        if (a.out_stats) { s1.resize((size_t)boards * C * 2); hipMemcpy(s1.data(), dstats, s1.size() * 4, hipMemcpyDeviceToHost); }
+        hipMemset(dout, 0, nb);
+        hipError_t e2 = launch_conv_z2(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o2.data(), dout, nb, hipMemcpyDeviceToHost);
+        if (a.out_stats) { s2.resize(s1.size()); hipMemcpy(s2.data(), dstats, s2.size() * 4, hipMemcpyDeviceToHost); }
+        size_t bad = 0; double md = 0, ms = 0;
+        for (size_t i = 0; i < o1.size(); ++i) { const double d = fabs((double)o1[i] - (double)o2[i]); if (d != 0) ++bad; if (d > md) md = d; }
+        for (size_t i = 0; i < s1.size(); ++i) { const double d = fabs((double)s1[i] - (double)s2[i]) / (1.0 + fabs((double)s1[i])); if (d > ms) ms = d; }
+        printf("compare conv_zs (%s) vs conv_z2 (%s): out %zu differing elements of %zu (max |d| %.3g), stats max rel %.3g; out[0..3] = %g %g %g %g\n",
+               hipGetErrorString(e1), hipGetErrorString(e2), bad, o1.size(), md, ms, (double)o2[0], (double)o2[1], (double)o2[2], (double)o2[3]);
+    }
+#endif
 #ifdef BENCH_CMP   // conv_zs_kernel against conv_pp16_kernel on the same operands: outputs must agree bit for bit (stats / gate: closely)
     {
         const size_t nb = (size_t)M * C * 2;
@@ -135,6 +161,9 @@ int main(int argc, char** argv) {
         printf("compare conv_pp16 (%s) vs conv_zs (%s): out %zu differing elements (max |d| %.3g), y2 %zu (max %.3g), stats max rel %.3g; out[0..3] = %g %g %g %g\n",
                hipGetErrorString(e1), hipGetErrorString(e2), bad, md, bad2, md2, ms, (double)o2[0], (double)o2[1], (double)o2[2], (double)o2[3]);
     }
+#endif
+#ifdef BENCH_Z2     // argv[3] = start delay of the second workgroup of every CU in us
+    if (argc > 3) { const int d = (int)(atof(argv[3]) * 100.0); hipMemcpyToSymbol(HIP_SYMBOL(g_z2_delay), &d, sizeof(int)); }
 #endif
     for (int i = 0; i < 3; ++i) launch_conv_pp(a, st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
