@@ -236,6 +236,14 @@ int m0_selfplay_last_batch_nhwc(m0_selfplay* sp, uint16_t* nhwc, int max_rows, i
  * m0_selfplay_* functions; a record's `played` holds the moves, `result` the outcome from White's point of view
  * (0 for unfinished or adjudicated games, as the reference scores them 1/2-1/2). */
 m0_selfplay* m0_arena_create(m0_net* net_a, m0_net* net_b, const m0_selfplay_cfg* cfg);
+/* The same match engine without networks, for external evaluators behind the reference's infer_np seam (golden tests replay
+ * the reference's arena games this way): m0_arena_ext_select returns the leaves of network A's searches and of network B's
+ * separately (planes f32 [rows,19,8,8] each; max_rows >= concurrent_games * (inference_batch_size + 1) for both buffers),
+ * m0_arena_ext_expand takes the two evaluators' answers and finishes the step exactly as m0_selfplay_step does. */
+m0_selfplay* m0_arena_create_ext(const m0_selfplay_cfg* cfg);
+int m0_arena_ext_select(m0_selfplay* sp, int* rows_a, int* rows_b, float* planes_a, float* planes_b, int max_rows);
+int m0_arena_ext_expand(m0_selfplay* sp, const float* logits_a, const float* values_a, int rows_a, const float* logits_b,
+                        const float* values_b, int rows_b);
 /* PGN output of arena games (arena.py:281-303 uses chess.pgn): standard algebraic notation, python-chess Board.san().
  * m0_san_legal_fen: the legal moves of `fen` in legal_moves order (moves u16[256]) with their SAN (san char[256][8],
  * NUL-padded).  m0_san_game: movetext "1. e4 e5 2. Nf3 ..." of a game from the start position (moves as in

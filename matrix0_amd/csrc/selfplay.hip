@@ -89,7 +89,7 @@ struct m0_selfplay {
     std::mutex mu;
     std::vector<Sample> hsamples;
     std::vector<int> prev_done;           // per slot: simulations already credited to stats.sims
-    int last_rows = 0;
+    int last_rows = 0, last_rows_b = 0;
     int rows2[2] = {0, 0};                // rows of the last select per network
     std::vector<Pos> book;                // opening positions (m0_selfplay_set_openings)
     // LRUCache nn_cache of the reference (mcts.py:44-59, 303, 360-371): positions whose root was re-evaluated; 10 000 entries
@@ -510,7 +510,7 @@ static std::string san_of(const Pos& p, Move m, const Move* legal, int nlegal) {
 
 extern "C" {
 
-static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_selfplay_cfg* cfg) {
+static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_selfplay_cfg* cfg, bool arena = false) {
     if (!cfg) { m0_set_error("cfg is null"); return nullptr; }
     if (cfg->concurrent_games <= 0 || cfg->inference_batch_size <= 0 || cfg->num_simulations <= 0) {
         m0_set_error("concurrent_games, inference_batch_size and num_simulations must be positive");
@@ -525,7 +525,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->nethandle_b = nh_b;
     sp->net = m0_net_impl(nh);
     sp->net_b = m0_net_impl(nh_b);
-    sp->cfg.arena_mode = nh_b ? 1 : 0;
+    sp->cfg.arena_mode = (nh_b || arena) ? 1 : 0;
     sp->device = nh ? m0_net_device(nh) : 0;
     (void)hipSetDevice(sp->device);
     if (nh) sp->stream = m0_net_stream(nh);
@@ -537,7 +537,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     if (want < 4096) want = 4096;
     sp->cap = (int)want;
     sp->rows_max = (sp->G * (sp->L + 1) + 3) & ~3;      // L leaves + the re-evaluation of a reused root, per game
-    const int nreg = nh_b ? 2 : 1;                    // batch regions: one per network
+    const int nreg = sp->cfg.arena_mode ? 2 : 1;      // batch regions: one per network
     memset(&sp->stats, 0, sizeof(sp->stats));
     memset(&sp->d, 0, sizeof(sp->d));
     const size_t N = (size_t)sp->G * 2 * sp->cap;
@@ -625,6 +625,11 @@ m0_selfplay* m0_arena_create(m0_net* net_a, m0_net* net_b, const m0_selfplay_cfg
     return selfplay_create_impl(net_a, net_b, cfg);
 }
 
+m0_selfplay* m0_arena_create_ext(const m0_selfplay_cfg* cfg) {
+    if (cfg && (cfg->ssl_in_forward || cfg->ssl_targets)) { m0_set_error("arena games carry no SSL outputs"); return nullptr; }
+    return selfplay_create_impl(nullptr, nullptr, cfg, true);
+}
+
 void m0_selfplay_destroy(m0_selfplay* sp) {
     if (!sp) return;
     (void)hipSetDevice(sp->device);
@@ -663,15 +668,14 @@ int m0_selfplay_set_openings(m0_selfplay* sp, const char* const* fens, int n) {
     return M0_OK;
 }
 
-int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_rows) {
-    if (!sp || !rows) { m0_set_error("null argument"); return M0_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(sp->mu);
+// first half of a step for an external evaluator: select, then the leaves' planes on the host (region 0 = network A / the only
+// network, region 1 = network B of a match engine, whose rows start at d.net_row_base on the device)
+static int ext_select_impl(m0_selfplay* sp, int* rows_a, int* rows_b, float* planes_a, float* planes_b, int max_rows) {
     (void)hipSetDevice(sp->device);
-    if (sp->cfg.arena_mode) { m0_set_error("the external-evaluator step serves self-play engines only"); return M0_ERR_STATE; }
     if (sp->ext_pending) { m0_set_error("m0_selfplay_ext_expand outstanding"); return M0_ERR_STATE; }
     // select applies virtual losses and reserves batch rows: refuse a buffer that cannot take the worst case BEFORE it runs
     // (an error after it would leave the engine waiting for an ext_expand the caller has no planes for)
-    if (!planes || max_rows < sp->G * (sp->L + 1)) {
+    if (!planes_a || (sp->cfg.arena_mode && !planes_b) || max_rows < sp->G * (sp->L + 1)) {
         m0_set_error("planes buffer too small: concurrent_games * (inference_batch_size + 1) rows are required");
         return M0_ERR_INVALID;
     }
@@ -679,42 +683,80 @@ int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_ro
     if (rc != M0_OK) return rc;
     int r = 0;
     if (run_select(sp, &r) != 0) { m0_set_error(std::string("select failed: ") + hipGetErrorString(hipGetLastError())); return M0_ERR_HIP; }
-    if (r > sp->rows_max) { m0_set_error("row counter overflow"); return M0_ERR_STATE; }
-    *rows = r;
+    const int rb = sp->cfg.arena_mode ? sp->rows2[1] : 0;
+    if (r > sp->rows_max || rb > sp->rows_max) { m0_set_error("row counter overflow"); return M0_ERR_STATE; }
+    *rows_a = r;
+    if (rows_b) *rows_b = rb;
     sp->last_rows = r;
+    sp->last_rows_b = rb;
     sp->ext_pending = true;
-    if (r > 0) {
+    if (r + rb > 0) {
         if (sync_games_d2h(sp) != 0) { m0_set_error("device sync failed"); return M0_ERR_HIP; }
         (void)hipMemcpy(sp->hsamples.data(), sp->d.samples, sizeof(Sample) * (size_t)sp->G * (sp->L + 1), hipMemcpyDeviceToHost);
+        const int base = sp->d.net_row_base;
         for (int g = 0; g < sp->G; ++g) {
             if (!sp->hg[g].active) continue;
             for (int s = 0; s < sp->hg[g].nsamples; ++s) {
                 const Sample& smp = sp->hsamples[(size_t)g * (sp->L + 1) + s];
-                if ((smp.kind == 1 || smp.kind == 2 || smp.kind == 4) && smp.row >= 0 && smp.row < r)
-                    encode_planes_f32(smp.pos, planes + (size_t)smp.row * 19 * 64);
+                if (!(smp.kind == 1 || smp.kind == 2 || smp.kind == 4) || smp.row < 0) continue;
+                if (smp.row < r) encode_planes_f32(smp.pos, planes_a + (size_t)smp.row * 19 * 64);
+                else if (rb > 0 && smp.row >= base && smp.row < base + rb) encode_planes_f32(smp.pos, planes_b + (size_t)(smp.row - base) * 19 * 64);
             }
         }
     }
     return M0_OK;
 }
 
-int m0_selfplay_ext_expand(m0_selfplay* sp, const float* logits, const float* values, int rows) {
-    if (!sp) { m0_set_error("null argument"); return M0_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(sp->mu);
+static int ext_expand_impl(m0_selfplay* sp, const float* logits_a, const float* values_a, int rows_a, const float* logits_b,
+                           const float* values_b, int rows_b) {
     (void)hipSetDevice(sp->device);
     if (!sp->ext_pending) { m0_set_error("no m0_selfplay_ext_select outstanding"); return M0_ERR_STATE; }
-    if (rows != sp->last_rows) { m0_set_error("rows does not match the last select"); return M0_ERR_INVALID; }
-    if (rows > 0) {
-        if (!logits || !values) { m0_set_error("null argument"); return M0_ERR_INVALID; }
-        (void)hipMemcpyAsync(sp->logits_dev, logits, (size_t)rows * 4672 * 4, hipMemcpyHostToDevice, sp->stream);
-        (void)hipMemcpyAsync(sp->values_dev, values, (size_t)rows * 4, hipMemcpyHostToDevice, sp->stream);
+    if (rows_a != sp->last_rows || rows_b != sp->last_rows_b) { m0_set_error("rows does not match the last select"); return M0_ERR_INVALID; }
+    if ((rows_a > 0 && (!logits_a || !values_a)) || (rows_b > 0 && (!logits_b || !values_b))) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    if (rows_a > 0) {
+        (void)hipMemcpyAsync(sp->logits_dev, logits_a, (size_t)rows_a * 4672 * 4, hipMemcpyHostToDevice, sp->stream);
+        (void)hipMemcpyAsync(sp->values_dev, values_a, (size_t)rows_a * 4, hipMemcpyHostToDevice, sp->stream);
+    }
+    if (rows_b > 0) {
+        const size_t base = (size_t)sp->d.net_row_base;
+        (void)hipMemcpyAsync(sp->logits_dev + base * 4672, logits_b, (size_t)rows_b * 4672 * 4, hipMemcpyHostToDevice, sp->stream);
+        (void)hipMemcpyAsync(sp->values_dev + base, values_b, (size_t)rows_b * 4, hipMemcpyHostToDevice, sp->stream);
     }
     sp->ext_pending = false;
     std::string err;
     (void)hipEventRecord(sp->ev0, sp->stream); (void)hipEventRecord(sp->ev1, sp->stream);
-    int rc = step_back(sp, rows, now_ms(), err);
+    int rc = step_back(sp, rows_a + rows_b, now_ms(), err);
     if (rc != M0_OK) m0_set_error(err);
     return rc;
+}
+
+int m0_selfplay_ext_select(m0_selfplay* sp, int* rows, float* planes, int max_rows) {
+    if (!sp || !rows) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp->cfg.arena_mode) { m0_set_error("a match engine has two evaluators: use m0_arena_ext_select"); return M0_ERR_STATE; }
+    return ext_select_impl(sp, rows, nullptr, planes, nullptr, max_rows);
+}
+
+int m0_selfplay_ext_expand(m0_selfplay* sp, const float* logits, const float* values, int rows) {
+    if (!sp) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (sp->cfg.arena_mode) { m0_set_error("a match engine has two evaluators: use m0_arena_ext_expand"); return M0_ERR_STATE; }
+    return ext_expand_impl(sp, logits, values, rows, nullptr, nullptr, 0);
+}
+
+int m0_arena_ext_select(m0_selfplay* sp, int* rows_a, int* rows_b, float* planes_a, float* planes_b, int max_rows) {
+    if (!sp || !rows_a || !rows_b) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (!sp->cfg.arena_mode) { m0_set_error("not a match engine"); return M0_ERR_STATE; }
+    return ext_select_impl(sp, rows_a, rows_b, planes_a, planes_b, max_rows);
+}
+
+int m0_arena_ext_expand(m0_selfplay* sp, const float* logits_a, const float* values_a, int rows_a, const float* logits_b,
+                        const float* values_b, int rows_b) {
+    if (!sp) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    if (!sp->cfg.arena_mode) { m0_set_error("not a match engine"); return M0_ERR_STATE; }
+    return ext_expand_impl(sp, logits_a, values_a, rows_a, logits_b, values_b, rows_b);
 }
 
 int m0_selfplay_step(m0_selfplay* sp, int steps) {

@@ -60,6 +60,10 @@ def _bind():
     L.m0_selfplay_create.argtypes = [C.c_void_p, C.POINTER(SelfplayCfg)]
     L.m0_arena_create.restype = C.c_void_p
     L.m0_arena_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SelfplayCfg)]
+    L.m0_arena_create_ext.restype = C.c_void_p
+    L.m0_arena_create_ext.argtypes = [C.POINTER(SelfplayCfg)]
+    L.m0_arena_ext_select.argtypes = [C.c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.c_void_p, C.c_void_p, c_int]
+    L.m0_arena_ext_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int]
     L.m0_san_legal_fen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(c_int)]
     L.m0_san_game.argtypes = [C.c_void_p, c_int, C.c_char_p, c_int]
     L.m0_selfplay_destroy.argtypes = [C.c_void_p]
@@ -474,6 +478,34 @@ class ArenaEngine(SelfplayEngine):
         self._h = self._L.m0_arena_create(backend_a.handle, backend_b.handle, C.byref(cfg))
         if not self._h:
             raise RuntimeError(f"m0_arena_create failed: {_lib.last_error()}")
+
+
+class ArenaExtEngine(SelfplayEngine):
+    """Match engine without networks (m0_arena_create_ext): two external evaluators behind the infer_np seam."""
+
+    def __init__(self, cfg: SelfplayCfg):
+        self._L = _bind()
+        self.backend = None
+        self.cfg = cfg
+        self._h = self._L.m0_arena_create_ext(C.byref(cfg))
+        if not self._h:
+            raise RuntimeError(f"m0_arena_create_ext failed: {_lib.last_error()}")
+
+    def arena_ext_select(self):
+        ra, rb = c_int(0), c_int(0)
+        cap = self.cfg.concurrent_games * (self.cfg.inference_batch_size + 1)
+        pa = np.zeros((cap, 19, 8, 8), dtype=np.float32)
+        pb = np.zeros((cap, 19, 8, 8), dtype=np.float32)
+        _lib.check(self._L.m0_arena_ext_select(self._h, C.byref(ra), C.byref(rb), pa.ctypes.data_as(C.c_void_p),
+                                               pb.ctypes.data_as(C.c_void_p), cap), "m0_arena_ext_select")
+        return pa[: ra.value], pb[: rb.value]
+
+    def arena_ext_expand(self, lg_a, v_a, lg_b, v_b) -> None:
+        la = np.ascontiguousarray(lg_a, dtype=np.float32); va = np.ascontiguousarray(v_a, dtype=np.float32)
+        lb = np.ascontiguousarray(lg_b, dtype=np.float32); vb = np.ascontiguousarray(v_b, dtype=np.float32)
+        _lib.check(self._L.m0_arena_ext_expand(self._h, la.ctypes.data_as(C.c_void_p), va.ctypes.data_as(C.c_void_p), int(la.shape[0]),
+                                               lb.ctypes.data_as(C.c_void_p), vb.ctypes.data_as(C.c_void_p), int(lb.shape[0])),
+                   "m0_arena_ext_expand")
 
 
 def arena_choose_move(visits, temp: float, ply: int, temp_plies: int, u: float) -> int:

@@ -61,3 +61,45 @@ def expected_score(ra: float, rb: float) -> float:
 def update_elo(ra: float, rb: float, sa: float, k: float = 20.0) -> Tuple[float, float]:
     delta = k * (sa - expected_score(ra, rb))
     return ra + delta, rb - delta
+
+
+def play_game(idx: int, mcts_cfg: dict, infer_a, infer_b, seed: int, *, sims: int, max_moves: int, temp: float, temp_plies: int,
+              draw_cfg: dict, numerics: str = "reference", virtual_loss_active: bool = False):
+    """One game of _arena_run_one_game (arena.py:59-126) on the oracle's MCTS: game `idx` has A as White when idx is even, each
+    side searches with its OWN MCTS object (arena.py:157-158) -- here tree-only, a fresh root per run(), the mode
+    tests/golden/ref_arena.json.gz was played in (reference transposition table patched out) -- and the two objects draw from
+    ONE set of streams, as both of the reference's draw from the process-global generators.  Returns the per-ply trace."""
+    from . import chess_py as ch
+    from . import mcts_ref as ref
+    cfg = ref.MCTSConfig.from_dict(dict(mcts_cfg, num_simulations=sims, use_tt=False, virtual_loss_active=virtual_loss_active,
+                                        numerics=numerics))
+    A = ref.MCTS(cfg, infer_a, seed=seed, game=idx)
+    B = ref.MCTS(cfg, infer_b, seed=seed, game=idx)
+    B.jitter, B.noise, B.dirichlet = A.jitter, A.noise, A.dirichlet
+    game = ref.Stream(ref.derive_seed(seed, idx, ref.PURPOSE_GAME))
+    board = ch.Board()
+    a_is_white = idx % 2 == 0
+    history, trace = [], []
+    n = 0
+    while not board.is_game_over(claim_draw=True) and n < max_moves:
+        eng = A if (board.turn == ch.WHITE) == a_is_white else B
+        if ref.should_adjudicate_draw(board, history, draw_cfg):
+            break
+        eng._last_root = None                           # tree-only oracle: no subtree carried between a side's searches
+        visits, _, root_q = eng.run(board, ply=n)
+        moves = list(visits.keys())
+        vis = [visits[m] for m in moves]
+        sampling = temp > 1e-3 and n < temp_plies
+        k = arena_choose_move(vis, temp, n, temp_plies, game.next() if sampling else 0.0)
+        trace.append({"side": "A" if eng is A else "B", "ply": n, "fen": board.fen(), "visits": vis, "chosen": k,
+                      "root_q": root_q, "moves": [m.from_square | (m.to_square << 6) | ((m.promotion or 0) << 12) for m in moves]})
+        board.push(moves[k])
+        history.append(moves[k])
+        n += 1
+    if board.is_game_over(claim_draw=True):
+        res = board.result(claim_draw=True)
+    else:
+        res = "1/2-1/2"
+    return {"plies": n, "result": res, "score": game_score(res, a_is_white), "trace": trace, "final_fen": board.fen(),
+            "evals_a": A.evals, "evals_b": B.evals,
+            "draws": {"jitter": A.jitter.ctr, "noise": A.noise.ctr, "dirichlet": A.dirichlet.ctr, "game": game.ctr}}

@@ -152,3 +152,36 @@ def test_worker_goldens_cover_every_ending():
     assert any(z == 0.0 for _, z, _ in ends.values())                   # a draw by rule
     assert any(z not in (0.0, 1.0, -1.0) for _, z, _ in ends.values())  # cut by length / heuristic: z = last root value
     assert "ssl_piece" in _load_worker("lengthcap")
+
+
+# ---- whole arena games of the reference's _arena_run_one_game with real searches (tools/gen_golden_selfplay.py::gen_arena) ----
+ARENA = load_json("ref_arena.json.gz")
+
+
+@pytest.mark.parametrize("gi", range(len(ARENA["games"])))
+def test_oracle_replays_reference_arena_games(gi):
+    """oracle/arena_ref.play_game against the game the reference's own loop played: two evaluators, the side to move's
+    searcher at every ply, visit counts, move choice (sampled / most visited), draw adjudication, length cap, result,
+    evaluation counts per network and stream positions."""
+    from oracle import arena_ref
+    g = ARENA["games"][gi]
+    na, nb = HashNet(**g["net_a"]), HashNet(**g["net_b"])
+    out = arena_ref.play_game(g["uid"], g["mcts"], na.infer_np, nb.infer_np, ARENA["seed"], sims=g["sims"], max_moves=g["max_moves"],
+                              temp=g["temp"], temp_plies=g["temp_plies"], draw_cfg=g["draw"])
+    assert out["plies"] == g["plies"] and out["result"] == g["result"] and out["score"] == g["score"]
+    assert out["final_fen"] == g["final_fen"]
+    for t, (got, want) in enumerate(zip(out["trace"], g["trace"])):
+        assert got["side"] == want["side"] and got["fen"] == want["fen"], t
+        assert got["moves"] == want["moves"] and got["visits"] == want["visits"], t
+        assert abs(got["root_q"] - want["root_q"]) < 1e-12, t
+    assert [t["chosen"] for t in out["trace"]] == g["chosen"]
+    assert (out["evals_a"], out["evals_b"]) == (g["evals_a"], g["evals_b"])
+    assert out["draws"] == g["draws"]
+
+
+def test_arena_goldens_cover_both_colours_sampling_argmax_and_adjudication():
+    gs = ARENA["games"]
+    assert {g["uid"] % 2 for g in gs} == {0, 1}
+    assert any(g["temp"] <= 1e-3 for g in gs) and any(g["temp"] > 1e-3 and g["temp_plies"] > 0 for g in gs)
+    assert any(g["plies"] < g["max_moves"] for g in gs) and any(g["plies"] == g["max_moves"] for g in gs)
+    assert all({t["side"] for t in g["trace"]} == {"A", "B"} for g in gs)

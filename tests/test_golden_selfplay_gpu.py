@@ -71,3 +71,53 @@ def test_engine_plays_the_reference_workers_game(name):
     if meta["ssl"]:
         for task in ("piece", "threat", "pin", "fork", "control"):
             assert np.array_equal(rec["ssl"][task], g[f"ssl_{task}"]), task
+
+
+# ---- whole arena games: the reference's own _arena_run_one_game with real searches (tests/golden/ref_arena.json.gz) ----
+from tests.golden_ref import load_json, uci as _uci      # noqa: E402
+
+ARENA = load_json("ref_arena.json.gz")
+
+
+@pytest.mark.parametrize("gi", range(len(ARENA["games"])))
+def test_match_engine_plays_the_reference_arena_game(gi):
+    """m0_arena_create_ext + the two-evaluator step of the C-ABI against the game the reference's arena loop played
+    (arena.py:59-126; one MCTS object per side, table patched out): the side to move's evaluator at every ply, visit counts of
+    every search (as the float32 policy target n / total), root values, the sampled / most visited move, adjudication and
+    length cap, the result, and the number of evaluations each network was asked for."""
+    from matrix0_amd import engine as eng
+    g = ARENA["games"][gi]
+    cfg_dict = {"seed": ARENA["seed"], "mcts": dict(g["mcts"]), "draw": dict(g["draw"]),
+                "selfplay": {"num_simulations": g["sims"], "max_game_len": g["max_moves"], "opening_random_plies": 0}}
+    cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=1, total_games=1, first_game_index=g["uid"],
+                                     virtual_loss_active=False, record_games=True)
+    cfg.arena_temp, cfg.arena_temp_plies = float(g["temp"]), int(g["temp_plies"])
+    e = eng.ArenaExtEngine(cfg)
+    na, nb = HashNet(**g["net_a"]), HashNet(**g["net_b"])
+    z0 = (np.zeros((0, 4672), np.float32), np.zeros((0,), np.float32))
+    rec = None
+    for _ in range(100000):
+        if not e.running():
+            break
+        pa, pb = e.arena_ext_select()
+        la, va = na.infer_np(pa) if pa.shape[0] else z0
+        lb, vb = nb.infer_np(pb) if pb.shape[0] else z0
+        e.arena_ext_expand(la, va, lb, vb)
+        rec = rec or e.poll()
+    rec = rec or e.poll()
+    e.close()
+    assert rec is not None and rec["game_index"] == g["uid"]
+    T = g["plies"]
+    assert rec["moves"] == T and len(rec["played"]) == T
+    legal0 = [t["moves"][k] for t, k in zip(g["trace"], g["chosen"])]
+    assert rec["played"] == [_uci(c) for c in legal0]
+    for t, want in enumerate(g["trace"]):
+        tot = float(sum(want["visits"]))
+        pi = np.zeros(4672, np.float32)
+        for i, n in zip(want["idx"], want["visits"]):
+            pi[i] = np.float32(n / tot)
+        assert np.array_equal(rec["pi"][t], pi), f"visit counts at ply {t} (side {want['side']})"
+        assert abs(float(rec["search_values"][t]) - want["root_q"]) < 1e-6, t
+    # unfinished / adjudicated games are 1/2-1/2 (arena.py:121-123): result 0 from White's point of view
+    assert g["result"] == "1/2-1/2" and rec["result"] == 0.0
+    assert (na.calls, nb.calls) == (g["evals_a"], g["evals_b"])

@@ -533,7 +533,7 @@ def gen_mcts_vl():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["encoding", "mcts", "mcts_vl", "selfplay", "worker"]
+    what = sys.argv[1:] or ["encoding", "mcts", "mcts_vl", "selfplay", "arena", "worker"]
     os.makedirs(OUT, exist_ok=True)
     if "encoding" in what:
         gen_encoding()
@@ -544,6 +544,9 @@ if __name__ == "__main__":
     if "selfplay" in what:
         from gen_golden_selfplay import gen_selfplay
         gen_selfplay()
+    if "arena" in what:
+        from gen_golden_selfplay import gen_arena
+        gen_arena()
     if "worker" in what:
         from gen_golden_selfplay import gen_worker
         gen_worker()

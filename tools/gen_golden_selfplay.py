@@ -332,6 +332,76 @@ def run_worker_case(name):
           f"evals={net.calls} msg={meta['message']} -> {os.path.getsize(os.path.join(OUT, f'ref_worker_{name}.npz'))} bytes", flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ whole arena games
+ARENA_CASES = [
+    # (game index (even: A is White), net A, net B, sims, L, max_moves, temp, temp_plies, mcts extra, draw cfg)
+    (0, {"seed": 51, "sharp": 8.0, "vscale": 0.5}, {"seed": 52, "sharp": 5.0, "vscale": 0.6}, 48, 8, 40, 1.0, 12, {}, {}),
+    (1, {"seed": 51, "sharp": 8.0, "vscale": 0.5}, {"seed": 52, "sharp": 5.0, "vscale": 0.6}, 48, 8, 40, 0.0, 0, {}, {}),
+    (2, {"seed": 53, "sharp": 6.0, "vscale": 0.4}, {"seed": 54, "sharp": 9.0, "vscale": 0.5}, 96, 32, 60, 0.5, 20,
+     {"dirichlet_plies": 8}, {"enabled": True, "min_plies": 12, "window": 8, "min_unique": 5, "halfmove_cap": 7,
+                               "material_draw_threshold": 10}),          # ends by heuristic adjudication (halfmove clock)
+    (3, {"seed": 55, "sharp": 4.0, "vscale": 0.5}, {"seed": 56, "sharp": 12.0, "vscale": 0.5}, 64, 16, 90, 1.3, 90,
+     {"selection_jitter": 0.0}, {}),
+]
+
+
+def gen_arena():
+    """ref_arena.json.gz: whole games of the reference's own _arena_run_one_game (arena.py:59-126) with REAL searches: two MCTS
+    objects (one per side, kept across the moves as arena.py:157-158 does) behind two different evaluators, the transposition
+    table patched out as for the worker goldens (every run() then starts from a fresh root: the match engine's mode)."""
+    import azchess.arena as rarena
+    from azchess.config import Config as RConfig
+    games = []
+    for (gi, net_a, net_b, sims, L, max_moves, temp, temp_plies, mextra, draw) in ARENA_CASES:
+        mcfg = dict(BASE_MCTS, inference_batch_size=L, num_simulations=sims, **mextra)
+        na, nb = HashNet(**net_a), HashNet(**net_b)
+        A = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=na)
+        B = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=nb)
+        trace = []
+        orig_run = rmcts.MCTS.run
+
+        def run_wrap(self, board, num_simulations=None, ply=None):
+            vc, pi, v = orig_run(self, board, num_simulations, ply)
+            kids = list(self._last_root.children.values())
+            trace.append({"side": "A" if self is A else "B", "ply": ply, "fen": board.fen(),
+                          "moves": [mv_code(m) for m in vc.keys()], "idx": [int(c.move_idx) for c in kids],
+                          "visits": [int(x) for x in vc.values()], "root_q": float(v)})
+            return vc, pi, v
+
+        rarena._P_MCTS_A, rarena._P_MCTS_B = A, B
+        rarena._P_CFG = RConfig({"draw": draw})
+        st = refshim.Streams(8080, gi)
+        rmcts.MCTS.run = run_wrap
+        try:
+            with TTOff(), refshim.injected(st):
+                score, nmoves, res = rarena._arena_run_one_game((gi, max_moves, temp, temp_plies, False))
+        finally:
+            rmcts.MCTS.run = orig_run
+        # which child was played at every ply: replay the choice (checked below against the positions the reference searched)
+        b = chess.Board()
+        st2 = refshim.Streams(8080, gi)
+        chosen = []
+        for ply in range(nmoves):
+            t = trace[ply]
+            assert t["fen"] == b.fen(), "arena replay diverged from the reference loop"
+            if temp > 1e-3 and ply < temp_plies:
+                k = oref_arena_choice(t["visits"], temp, st2.game.next())
+            else:
+                k = int(np.argmax(np.array(t["visits"], np.float32)))
+            chosen.append(k)
+            legal = list(b.legal_moves)
+            assert [mv_code(m) for m in legal] == t["moves"]
+            b.push(legal[k])
+        assert st2.game.ctr == st.game.ctr
+        assert len(trace) in (nmoves, nmoves + 0)
+        games.append({"uid": gi, "net_a": net_a, "net_b": net_b, "sims": sims, "L": L, "max_moves": max_moves, "temp": temp,
+                      "temp_plies": temp_plies, "mcts": mcfg, "draw": draw, "plies": nmoves, "result": res, "score": score,
+                      "trace": trace, "chosen": chosen, "final_fen": b.fen(), "evals_a": na.calls, "evals_b": nb.calls,
+                      "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
+        print(f"arena game {gi}: plies={nmoves} result={res} score_A={score} evals A/B = {na.calls}/{nb.calls}", flush=True)
+    dump_json("ref_arena.json.gz", {"seed": 8080, "games": games})
+
+
 def gen_worker(names=None):
     for name in (names or WORKER_CASES):
         run_worker_case(name)
@@ -342,5 +412,7 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if not args or "selfplay" in args:
         gen_selfplay()
+    if not args or "arena" in args:
+        gen_arena()
     if not args or "worker" in args:
         gen_worker([a for a in args if a in WORKER_CASES] or None)
