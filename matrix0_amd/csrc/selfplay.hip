@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <list>
@@ -96,6 +97,7 @@ struct m0_selfplay {
     std::list<uint64_t> nn_lru;
     std::unordered_map<uint64_t, std::list<uint64_t>::iterator> nn_map;
     bool ext_pending = false;             // ext_select done, ext_expand outstanding
+    bool counted = false;                 // registered in g_engines_with_net (forward gate)
 };
 
 namespace {
@@ -389,6 +391,28 @@ int apply_advances(m0_selfplay* sp, std::vector<int>& ids, std::vector<int>& slo
 
 int step_back(m0_selfplay* sp, int rows, double t0, std::string& err);
 
+// Several engines on one GPU (engine.SelfplayPool): their network forwards take turns.  A forward fills the chip, so two in
+// flight only time-slice each other; what the second engine adds is that its tree kernels and host work run while the other
+// engine's forward owns the chip.  The gate is held from the first launch of a forward until its last kernel has finished.
+constexpr int M0_MAX_DEVICES = 16;
+std::mutex g_forward_gate[M0_MAX_DEVICES];
+std::atomic<int> g_engines_with_net[M0_MAX_DEVICES];
+
+struct ForwardGate {
+    std::mutex* m = nullptr;
+    hipStream_t st = nullptr;
+    ForwardGate(int device, hipStream_t stream) : st(stream) {
+        if ((unsigned)device < (unsigned)M0_MAX_DEVICES && g_engines_with_net[device].load(std::memory_order_relaxed) > 1) {
+            m = &g_forward_gate[device];
+            m->lock();
+        }
+    }
+    void release() {
+        if (m) { (void)hipStreamSynchronize(st); m->unlock(); m = nullptr; }
+    }
+    ~ForwardGate() { release(); }
+};
+
 int one_step(m0_selfplay* sp, std::string& err) {
     const double t0 = now_ms();
     (void)hipEventRecord(sp->ev0, sp->stream);
@@ -396,6 +420,7 @@ int one_step(m0_selfplay* sp, std::string& err) {
     if (run_select(sp, &rows) != 0) { err = std::string("select failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev1, sp->stream);
     if (rows > sp->rows_max || sp->rows2[1] > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
+    ForwardGate gate(sp->device, sp->stream);
     if (rows > 0) {
         if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
         m0_net_lock(sp->nethandle);          // an infer_np on the same backend from another thread waits here
@@ -414,6 +439,7 @@ int one_step(m0_selfplay* sp, std::string& err) {
         if (rc != M0_OK) return rc;
         rows += sp->rows2[1];
     }
+    gate.release();
     return step_back(sp, rows, t0, err);
 }
 
@@ -527,6 +553,7 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->net_b = m0_net_impl(nh_b);
     sp->cfg.arena_mode = (nh_b || arena) ? 1 : 0;
     sp->device = nh ? m0_net_device(nh) : 0;
+    if (nh && (unsigned)sp->device < (unsigned)M0_MAX_DEVICES) { g_engines_with_net[sp->device].fetch_add(1); sp->counted = true; }
     (void)hipSetDevice(sp->device);
     if (nh) sp->stream = m0_net_stream(nh);
     else { (void)hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking); sp->own_stream = true; }
@@ -632,6 +659,7 @@ m0_selfplay* m0_arena_create_ext(const m0_selfplay_cfg* cfg) {
 
 void m0_selfplay_destroy(m0_selfplay* sp) {
     if (!sp) return;
+    if (sp->counted) g_engines_with_net[sp->device].fetch_sub(1);
     (void)hipSetDevice(sp->device);
     if (sp->stream) (void)hipStreamSynchronize(sp->stream);
     for (void* p : sp->allocs) (void)hipFree(p);
