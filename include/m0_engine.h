@@ -252,6 +252,10 @@ int m0_arena_ext_expand(m0_selfplay* sp, const float* logits_a, const float* val
 int m0_arena_choose_move(const int32_t* visits, int n, double temp, int ply, int temp_plies, double u);
 int m0_san_legal_fen(const char* fen, uint16_t* moves, char* san, int* nlegal);
 int m0_san_game(const uint16_t* moves, int n, char* out, int cap);
+/* Board.fen() after pushing `n` legal moves (UCI) on the position `fen` (python-chess semantics: cleaned castling rights, the
+ * en-passant square only when such a capture is legal); M0_ERR_INVALID for an illegal move.  Host function (no GPU): the PGN
+ * opening-book reader (selfplay/internal.py:39-63) and FEN-addressed callers are built on it. */
+int m0_fen_after(const char* fen, const char* const* ucis, int n, char* fen_out, int cap);
 
 /* ---- split-step search (external evaluator / parity tests): net may be NULL ----
  * m0_search_begin: reset slot g to `fen` (history-less), sims simulations, optional Dirichlet.

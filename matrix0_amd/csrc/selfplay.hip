@@ -1155,6 +1155,56 @@ int m0_san_legal_fen(const char* fen, uint16_t* moves, char* san, int* nlegal) {
     return M0_OK;
 }
 
+// Board.fen() of python-chess (en_passant="legal": the ep square only when an en-passant capture is legal; cleaned castling rights)
+static std::string fen_of(const Pos& p) {
+    std::string s;
+    for (int r = 7; r >= 0; --r) {
+        int e = 0;
+        for (int f = 0; f < 8; ++f) {
+            const int sq = r * 8 + f;
+            const uint64_t b = bit(sq);
+            if (!((p.occ[0] | p.occ[1]) & b)) { ++e; continue; }
+            if (e) { s += (char)('0' + e); e = 0; }
+            const int t = piece_type_at(p, sq);
+            s += ((p.occ[WHITE] & b) ? "PNBRQK" : "pnbrqk")[t];
+        }
+        if (e) s += (char)('0' + e);
+        if (r) s += '/';
+    }
+    s += p.turn == WHITE ? " w " : " b ";
+    const int cr = clean_cr(p);
+    std::string c;
+    if (cr & CR_WK) c += 'K';
+    if (cr & CR_WQ) c += 'Q';
+    if (cr & CR_BK) c += 'k';
+    if (cr & CR_BQ) c += 'q';
+    s += c.empty() ? "-" : c;
+    s += ' ';
+    if (p.ep >= 0 && has_legal_ep(p)) { s += (char)('a' + (p.ep & 7)); s += (char)('1' + (p.ep >> 3)); }
+    else s += '-';
+    s += ' ' + std::to_string(p.halfmove) + ' ' + std::to_string(p.fullmove);
+    return s;
+}
+
+int m0_fen_after(const char* fen, const char* const* ucis, int n, char* fen_out, int cap) {
+    if (!fen || !fen_out || cap <= 0 || (n > 0 && !ucis)) { m0_set_error("null argument"); return M0_ERR_INVALID; }
+    Pos p;
+    if (parse_fen(fen, p) != 0) { m0_set_error("bad FEN"); return M0_ERR_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        const Move m = ucis[i] ? parse_uci(ucis[i]) : (Move)0xFFFF;
+        Move mv[M0_MAX_MOVES];
+        const int k = gen_legal(p, mv);
+        bool ok = false;
+        for (int j = 0; j < k; ++j) if (mv[j] == m) ok = true;
+        if (!ok) { m0_set_error(std::string("Illegal move: ") + (ucis[i] ? ucis[i] : "(null)")); return M0_ERR_INVALID; }
+        make_move(p, m);
+    }
+    const std::string f = fen_of(p);
+    if ((int)f.size() + 1 > cap) { m0_set_error("output buffer too small"); return M0_ERR_INVALID; }
+    memcpy(fen_out, f.c_str(), f.size() + 1);
+    return M0_OK;
+}
+
 int m0_san_game(const uint16_t* moves, int n, char* out, int cap) {
     if ((!moves && n > 0) || !out || cap <= 0) { m0_set_error("null argument"); return M0_ERR_INVALID; }
     Pos p;

@@ -66,6 +66,7 @@ def _bind():
     L.m0_arena_ext_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int]
     L.m0_san_legal_fen.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(c_int)]
     L.m0_san_game.argtypes = [C.c_void_p, c_int, C.c_char_p, c_int]
+    L.m0_fen_after.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), c_int, C.c_char_p, c_int]
     L.m0_selfplay_destroy.argtypes = [C.c_void_p]
     L.m0_selfplay_destroy.restype = None
     L.m0_selfplay_step.argtypes = [C.c_void_p, c_int]
@@ -524,6 +525,19 @@ def san_legal(fen: str):
     _lib.check(L.m0_san_legal_fen(fen.encode(), mv.ctypes.data_as(C.c_void_p), san, C.byref(n)), "m0_san_legal_fen")
     raw = san.raw
     return [(move_to_uci(int(mv[i])), raw[8 * i: 8 * i + 8].split(b"\0", 1)[0].decode()) for i in range(n.value)]
+
+
+def fen_after(fen: str, ucis) -> str:
+    """Board.fen() after pushing the legal moves `ucis` on `fen` (python-chess semantics); ValueError for an illegal move."""
+    L = _bind()
+    ucis = list(ucis)
+    arr = (C.c_char_p * max(1, len(ucis)))(*[u.encode() for u in ucis])
+    buf = C.create_string_buffer(128)
+    rc = L.m0_fen_after(fen.encode(), arr, len(ucis), buf, len(buf))
+    if rc == -1:
+        raise ValueError(_lib.last_error())
+    _lib.check(rc, "m0_fen_after")
+    return buf.value.decode()
 
 
 def san_game(moves_raw) -> str:

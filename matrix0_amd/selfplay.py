@@ -65,9 +65,6 @@ def check_unsupported_sections(cfg_dict: dict) -> None:
     if tb.get("enabled", False):
         raise NotImplementedError("tablebases.enabled (selfplay/internal.py:250-260, 560-581: Syzygy probing through python-chess) "
                                   "is not implemented by the MI355X engine; set tablebases.enabled: false")
-    if (cfg_dict.get("selfplay", {}) or {}).get("book_path") and not (cfg_dict.get("engine", {}) or {}).get("opening_fens"):
-        raise NotImplementedError("selfplay.book_path is a PGN read with python-chess (selfplay/internal.py:34-63); give the engine "
-                                  "the book as FEN strings in engine.opening_fens instead")
 
 
 def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], games: int, q=None,
@@ -115,9 +112,16 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
         scfg = selfplay_cfg_from_dict(cfg2, concurrent_games=min(concurrent, max(1, games)), total_games=games,
                                       first_game_index=first_game_index, **eng_kw)
         engine = SelfplayEngine(backend, scfg)
-    if eng_cfg.get("opening_fens"):
+    # opening book (internal.py:246-248, 39-69): engine.opening_fens, or the PGN of selfplay.book_path read by pgn_book.py
+    book = list(eng_cfg.get("opening_fens") or [])
+    sp_book = (cfg_dict.get("selfplay", {}) or {}).get("book_path")
+    if not book and sp_book:
+        from .pgn_book import load_opening_book
+        book = load_opening_book(sp_book)
+        logger.debug("worker %d: %d positions from opening book %s", proc_id, len(book), sp_book)
+    if book:
         for e in (engine.engines if hasattr(engine, "engines") else [engine]):
-            e.set_openings(list(eng_cfg["opening_fens"]))
+            e.set_openings(book)
     # engine.replay_shards: emit replay-buffer shards directly (ReplayShardWriter: what the orchestrator's
     # compact_selfplay_to_replay would make of the per-game files) instead of one NPZ per game
     direct_replay = bool(eng_cfg.get("replay_shards", False))

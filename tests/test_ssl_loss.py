@@ -65,7 +65,7 @@ def test_loss_from_the_hip_heads_matches_the_reference(gold):
     """The five SSL heads of the HIP forward on the golden positions -> the same loss as the reference's torch fp32 module, within
     what fp16 activations allow (head logits agree to 1e-2: tests/test_net_gpu.py; the mean losses to 2e-3)."""
     from matrix0_amd.backend import M0Backend
-    from tests.golden_ref import load_net_golden
+    from tests.golden_util import load_net_golden
     cfg, sd, _, _, _, _ = load_net_golden("gn_silu_preact")          # the network the reference computed the losses with
     be = M0Backend.from_state_dict(cfg, sd)
     _, _, heads = be.infer_np_ssl(gold["x"])
