@@ -75,7 +75,6 @@ def test_worker_returns_at_once_for_zero_games_and_rejects_unimplemented_section
         selfplay.check_unsupported_sections({"openings": {"polyglot": "book.bin", "max_plies": 8}})
     with pytest.raises(NotImplementedError, match="tablebases"):
         selfplay.check_unsupported_sections({"tablebases": {"enabled": True, "path": "tb"}})
-    with pytest.raises(NotImplementedError, match="book_path"):
-        selfplay.check_unsupported_sections({"selfplay": {"book_path": "openings.pgn"}})
+    selfplay.check_unsupported_sections({"selfplay": {"book_path": "openings.pgn"}})     # PGN books are read (matrix0_amd/pgn_book.py)
     selfplay.check_unsupported_sections({"openings": {"polyglot": "", "max_plies": 0}, "tablebases": {"enabled": False},
                                          "selfplay": {"book_path": "x.pgn"}, "engine": {"opening_fens": ["8/8/8/8/8/8/8/K1k5 w - - 0 1"]}})
