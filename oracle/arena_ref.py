@@ -64,14 +64,15 @@ def update_elo(ra: float, rb: float, sa: float, k: float = 20.0) -> Tuple[float,
 
 
 def play_game(idx: int, mcts_cfg: dict, infer_a, infer_b, seed: int, *, sims: int, max_moves: int, temp: float, temp_plies: int,
-              draw_cfg: dict, numerics: str = "reference", virtual_loss_active: bool = False):
+              draw_cfg: dict, numerics: str = "reference", virtual_loss_active: bool = False, use_tt: bool = False):
     """One game of _arena_run_one_game (arena.py:59-126) on the oracle's MCTS: game `idx` has A as White when idx is even, each
-    side searches with its OWN MCTS object (arena.py:157-158) -- here tree-only, a fresh root per run(), the mode
-    tests/golden/ref_arena.json.gz was played in (reference transposition table patched out) -- and the two objects draw from
-    ONE set of streams, as both of the reference's draw from the process-global generators.  Returns the per-ply trace."""
+    side searches with its OWN MCTS object (arena.py:157-158), and the two objects draw from ONE set of streams, as both of the
+    reference's draw from the process-global generators.  use_tt = False: tree-only, a fresh root per run() (the reference with
+    its table patched out); use_tt = True: each side's table lives for the whole game, as in the untouched reference -- both
+    modes are in tests/golden/ref_arena.json.gz.  Returns the per-ply trace."""
     from . import chess_py as ch
     from . import mcts_ref as ref
-    cfg = ref.MCTSConfig.from_dict(dict(mcts_cfg, num_simulations=sims, use_tt=False, virtual_loss_active=virtual_loss_active,
+    cfg = ref.MCTSConfig.from_dict(dict(mcts_cfg, num_simulations=sims, use_tt=use_tt, virtual_loss_active=virtual_loss_active,
                                         numerics=numerics))
     A = ref.MCTS(cfg, infer_a, seed=seed, game=idx)
     B = ref.MCTS(cfg, infer_b, seed=seed, game=idx)

@@ -160,14 +160,15 @@ ARENA = load_json("ref_arena.json.gz")
 
 @pytest.mark.parametrize("gi", range(len(ARENA["games"])))
 def test_oracle_replays_reference_arena_games(gi):
-    """oracle/arena_ref.play_game against the game the reference's own loop played: two evaluators, the side to move's
+    """oracle/arena_ref.play_game against the game the reference's own loop played, with its transposition table patched out
+    (fresh root per search) and untouched (one table per side for the whole game): two evaluators, the side to move's
     searcher at every ply, visit counts, move choice (sampled / most visited), draw adjudication, length cap, result,
     evaluation counts per network and stream positions."""
     from oracle import arena_ref
     g = ARENA["games"][gi]
     na, nb = HashNet(**g["net_a"]), HashNet(**g["net_b"])
     out = arena_ref.play_game(g["uid"], g["mcts"], na.infer_np, nb.infer_np, ARENA["seed"], sims=g["sims"], max_moves=g["max_moves"],
-                              temp=g["temp"], temp_plies=g["temp_plies"], draw_cfg=g["draw"])
+                              temp=g["temp"], temp_plies=g["temp_plies"], draw_cfg=g["draw"], use_tt=g["tt"] == "on")
     assert out["plies"] == g["plies"] and out["result"] == g["result"] and out["score"] == g["score"]
     assert out["final_fen"] == g["final_fen"]
     for t, (got, want) in enumerate(zip(out["trace"], g["trace"])):
@@ -185,3 +186,9 @@ def test_arena_goldens_cover_both_colours_sampling_argmax_and_adjudication():
     assert any(g["temp"] <= 1e-3 for g in gs) and any(g["temp"] > 1e-3 and g["temp_plies"] > 0 for g in gs)
     assert any(g["plies"] < g["max_moves"] for g in gs) and any(g["plies"] == g["max_moves"] for g in gs)
     assert all({t["side"] for t in g["trace"]} == {"A", "B"} for g in gs)
+    assert {g["tt"] for g in gs} == {"on", "off"}
+    # the table changes the games: more evaluations (a root found in the table is evaluated again) and other visit counts
+    off = {g["uid"]: g for g in gs if g["tt"] == "off"}
+    on = {g["uid"]: g for g in gs if g["tt"] == "on"}
+    assert all(on[u]["evals_a"] > off[u]["evals_a"] for u in off)
+    assert any([t["visits"] for t in on[u]["trace"]] != [t["visits"] for t in off[u]["trace"]] for u in off)

@@ -347,58 +347,61 @@ ARENA_CASES = [
 
 def gen_arena():
     """ref_arena.json.gz: whole games of the reference's own _arena_run_one_game (arena.py:59-126) with REAL searches: two MCTS
-    objects (one per side, kept across the moves as arena.py:157-158 does) behind two different evaluators, the transposition
-    table patched out as for the worker goldens (every run() then starts from a fresh root: the match engine's mode)."""
+    objects (one per side, kept across the moves as arena.py:157-158 does) behind two different evaluators.  tt = "off": the
+    transposition table patched out as for the worker goldens (every run() starts from a fresh root: the match engine's
+    default); tt = "on": the reference untouched -- each side's table lives for the whole game, roots are looked up in it and
+    later searches merge into nodes earlier searches of that side left there."""
     import azchess.arena as rarena
     from azchess.config import Config as RConfig
     games = []
-    for (gi, net_a, net_b, sims, L, max_moves, temp, temp_plies, mextra, draw) in ARENA_CASES:
-        mcfg = dict(BASE_MCTS, inference_batch_size=L, num_simulations=sims, **mextra)
-        na, nb = HashNet(**net_a), HashNet(**net_b)
-        A = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=na)
-        B = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=nb)
-        trace = []
-        orig_run = rmcts.MCTS.run
+    for tt in ("off", "on"):
+      for (gi, net_a, net_b, sims, L, max_moves, temp, temp_plies, mextra, draw) in ARENA_CASES:
+          mcfg = dict(BASE_MCTS, inference_batch_size=L, num_simulations=sims, **mextra)
+          na, nb = HashNet(**net_a), HashNet(**net_b)
+          A = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=na)
+          B = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=nb)
+          trace = []
+          orig_run = rmcts.MCTS.run
 
-        def run_wrap(self, board, num_simulations=None, ply=None):
-            vc, pi, v = orig_run(self, board, num_simulations, ply)
-            kids = list(self._last_root.children.values())
-            trace.append({"side": "A" if self is A else "B", "ply": ply, "fen": board.fen(),
-                          "moves": [mv_code(m) for m in vc.keys()], "idx": [int(c.move_idx) for c in kids],
-                          "visits": [int(x) for x in vc.values()], "root_q": float(v)})
-            return vc, pi, v
+          def run_wrap(self, board, num_simulations=None, ply=None):
+              vc, pi, v = orig_run(self, board, num_simulations, ply)
+              kids = list(self._last_root.children.values())
+              trace.append({"side": "A" if self is A else "B", "ply": ply, "fen": board.fen(),
+                            "moves": [mv_code(m) for m in vc.keys()], "idx": [int(c.move_idx) for c in kids],
+                            "visits": [int(x) for x in vc.values()], "root_q": float(v)})
+              return vc, pi, v
 
-        rarena._P_MCTS_A, rarena._P_MCTS_B = A, B
-        rarena._P_CFG = RConfig({"draw": draw})
-        st = refshim.Streams(8080, gi)
-        rmcts.MCTS.run = run_wrap
-        try:
-            with TTOff(), refshim.injected(st):
-                score, nmoves, res = rarena._arena_run_one_game((gi, max_moves, temp, temp_plies, False))
-        finally:
-            rmcts.MCTS.run = orig_run
-        # which child was played at every ply: replay the choice (checked below against the positions the reference searched)
-        b = chess.Board()
-        st2 = refshim.Streams(8080, gi)
-        chosen = []
-        for ply in range(nmoves):
-            t = trace[ply]
-            assert t["fen"] == b.fen(), "arena replay diverged from the reference loop"
-            if temp > 1e-3 and ply < temp_plies:
-                k = oref_arena_choice(t["visits"], temp, st2.game.next())
-            else:
-                k = int(np.argmax(np.array(t["visits"], np.float32)))
-            chosen.append(k)
-            legal = list(b.legal_moves)
-            assert [mv_code(m) for m in legal] == t["moves"]
-            b.push(legal[k])
-        assert st2.game.ctr == st.game.ctr
-        assert len(trace) in (nmoves, nmoves + 0)
-        games.append({"uid": gi, "net_a": net_a, "net_b": net_b, "sims": sims, "L": L, "max_moves": max_moves, "temp": temp,
-                      "temp_plies": temp_plies, "mcts": mcfg, "draw": draw, "plies": nmoves, "result": res, "score": score,
-                      "trace": trace, "chosen": chosen, "final_fen": b.fen(), "evals_a": na.calls, "evals_b": nb.calls,
-                      "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
-        print(f"arena game {gi}: plies={nmoves} result={res} score_A={score} evals A/B = {na.calls}/{nb.calls}", flush=True)
+          rarena._P_MCTS_A, rarena._P_MCTS_B = A, B
+          rarena._P_CFG = RConfig({"draw": draw})
+          st = refshim.Streams(8080, gi)
+          rmcts.MCTS.run = run_wrap
+          try:
+              with (TTOff() if tt == "off" else Nop()), refshim.injected(st):
+                  score, nmoves, res = rarena._arena_run_one_game((gi, max_moves, temp, temp_plies, False))
+          finally:
+              rmcts.MCTS.run = orig_run
+          # which child was played at every ply: replay the choice (checked below against the positions the reference searched)
+          b = chess.Board()
+          st2 = refshim.Streams(8080, gi)
+          chosen = []
+          for ply in range(nmoves):
+              t = trace[ply]
+              assert t["fen"] == b.fen(), "arena replay diverged from the reference loop"
+              if temp > 1e-3 and ply < temp_plies:
+                  k = oref_arena_choice(t["visits"], temp, st2.game.next())
+              else:
+                  k = int(np.argmax(np.array(t["visits"], np.float32)))
+              chosen.append(k)
+              legal = list(b.legal_moves)
+              assert [mv_code(m) for m in legal] == t["moves"]
+              b.push(legal[k])
+          assert st2.game.ctr == st.game.ctr
+          assert len(trace) in (nmoves, nmoves + 0)
+          games.append({"tt": tt, "uid": gi, "net_a": net_a, "net_b": net_b, "sims": sims, "L": L, "max_moves": max_moves, "temp": temp,
+                        "temp_plies": temp_plies, "mcts": mcfg, "draw": draw, "plies": nmoves, "result": res, "score": score,
+                        "trace": trace, "chosen": chosen, "final_fen": b.fen(), "evals_a": na.calls, "evals_b": nb.calls,
+                        "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
+          print(f"arena game {gi} tt={tt}: plies={nmoves} result={res} score_A={score} evals A/B = {na.calls}/{nb.calls}", flush=True)
     dump_json("ref_arena.json.gz", {"seed": 8080, "games": games})
 
 
