@@ -168,7 +168,10 @@ typedef struct m0_selfplay_cfg {
     int fresh_tree_per_move;      /* 1 = every move starts from a brand-new root (what the reference does with MCTS._tt_get
                                      patched out, the mode tests/golden/ref_worker_*.npz were played in); 0 = keep the played
                                      child's subtree */
-    int tt_merge;                 /* 1 = transposition merging inside a search as mcts.py:919 + :1330-1346 (search graph is a DAG) */
+    int tt_merge;                 /* 1 = transposition merging inside a search as mcts.py:919 + :1330-1346 (search graph is a DAG).
+                                     Self-play: the table lives for one search.  Match engine (m0_arena_create*): one table per
+                                     side for the WHOLE game, roots looked up in it, as the reference's per-side MCTS objects do
+                                     (arena.py:157-158); arena_nodes must then hold all nodes a side creates in a game */
     int raw_legal_priors;         /* 1 = Node._expand_with_legal_priors (mcts.py:227-256): non-root priors = legal logits / their sum */
     int max_children;             /* MCTS._prune_children (mcts.py:806-826): keep the top-K children by prior; 0 = off */
     double min_child_prior;       /* ... after dropping children with prior < this; 0 = off */
@@ -230,8 +233,8 @@ int m0_selfplay_last_batch_nhwc(m0_selfplay* sp, uint16_t* nhwc, int max_rows, i
 
 /* Evaluation match between two networks (azchess/arena.py:59-126 _arena_run_one_game, :305 play_match): game i is played
  * with net_a as White when i is even.  Every search of a game is evaluated by the network of the side to move; each
- * move starts a fresh tree (the reference keeps one MCTS object, hence one transposition table, per side -- a subtree is
- * not carried from one side's search to the other's).  The game ends on board.is_game_over(claim_draw=True), on
+ * move starts a fresh tree, unless cfg->tt_merge asks for the reference's own structure: one transposition table per side
+ * kept for the whole game (arena.py:157-158 keeps one MCTS object per side), roots looked up in it.  The game ends on board.is_game_over(claim_draw=True), on
  * cfg->max_game_len plies or on draw adjudication (draw.py); no resignation.  Step / poll / stats / destroy with the
  * m0_selfplay_* functions; a record's `played` holds the moves, `result` the outcome from White's point of view
  * (0 for unfinished or adjudicated games, as the reference scores them 1/2-1/2). */

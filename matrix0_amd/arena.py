@@ -9,8 +9,11 @@ adjudication test of draw.py before every search (:67-72); the move is sampled f
 the first `temp_plies` plies when temp > 1e-3, otherwise the most visited move (:73-106); unfinished games score 1/2
 (:110-124); evaluation searches use no Dirichlet noise unless `eval.dirichlet_frac` says so and no entropy noise
 (:365-381); Wilson interval (:272-278), Elo update (elo.py:10-22), PGN files game_NNNN.pgn (:281-303).
-Deviation: every move starts a fresh tree (the reference keeps one MCTS object per side and so reuses that side's
-transposition table across its own moves)."""
+Search structure: by default every move starts a fresh tree.  The reference keeps one MCTS object -- hence one transposition
+table -- per side for the whole game (:157-158): `engine.compat.tt_merge: true` gives the match engine exactly that (one
+device table per side and game, roots looked up in it, later searches merging into the nodes earlier ones left there; size
+`engine.arena_nodes` for all nodes a side creates in a game).  Both modes replay the reference's own arena games move for move
+(tests/golden/ref_arena.json.gz, tests/test_golden_selfplay_gpu.py)."""
 from __future__ import annotations
 
 import json
@@ -90,11 +93,13 @@ def arena_cfg_from_dict(cfg: dict, *, games: int, num_sims: int, max_moves: int,
     m.update({"dirichlet_frac": float(ev.get("dirichlet_frac", 0.0)), "selection_jitter": float(sp.get("selection_jitter", 0.0)),
               "enable_entropy_noise": False})
     draw = dict(cfg.get("draw", {}) or {})
-    cfg2 = {"seed": cfg.get("seed", 1234), "mcts": m, "draw": draw,
+    ecfg = dict(cfg.get("engine", {}) or {})
+    cfg2 = {"seed": cfg.get("seed", 1234), "mcts": m, "draw": draw, "engine": {"compat": dict(ecfg.get("compat", {}) or {})},
             "selfplay": {"num_simulations": int(num_sims), "max_game_len": int(max_moves), "opening_random_plies": 0,
                          "resign_threshold": -2.0, "min_resign_plies": 10 ** 9}}
     c = eng.selfplay_cfg_from_dict(cfg2, concurrent_games=concurrent_games, total_games=games, seed=seed,
-                                   leaves_per_step=leaves_per_step, virtual_loss_active=True, record_games=False)
+                                   leaves_per_step=leaves_per_step, virtual_loss_active=bool(ecfg.get("virtual_loss_active", True)),
+                                   record_games=False, arena_nodes=int(ecfg.get("arena_nodes", 0) or 0))
     c.arena_temp = float(temp)
     c.arena_temp_plies = int(temp_plies)
     return c

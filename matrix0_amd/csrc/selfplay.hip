@@ -231,6 +231,9 @@ void begin_move(m0_selfplay* sp, int slot, int child_slot, std::vector<int>& adv
     int sims = playout_cap(c.num_simulations, c.playout_random_frac, cap_draws ? hgm.rng.next() : 0.0);
     hgm.cur_sims = sims;
     if (c.fresh_tree_per_move || c.tt_merge) child_slot = -1;   // tt_merge: the table lives for one search (see m0_engine.h)
+    // ... except in a match engine, where each side's table lives for the whole game: -3 = first search of the game (both
+    // tables cleared), -2 = any later one (root looked up in the side's table by advance_kernel)
+    if (c.arena_mode && c.tt_merge) child_slot = hgm.nstates == 0 ? -3 : -2;
     const bool dir = c.dirichlet_plies < 0 || hgm.nstates < c.dirichlet_plies;
     arm_search(sp, slot, hgm.pos, hgm.win, sims, dir, child_slot < 0);
     adv_ids.push_back(slot);
@@ -385,6 +388,21 @@ int apply_advances(m0_selfplay* sp, std::vector<int>& ids, std::vector<int>& slo
         (void)hipMemcpyAsync(sp->slots_dev, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, sp->stream);
         if (launch_advance(sp->d, sp->ids_dev, sp->slots_dev, (int)ids.size(), sp->stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(sp->stream) != hipSuccess) return -1;   // ids/slots vectors die with the caller
+        if (sp->d.tt_sides == 2) {
+            // per-side tables: only the device knows whether a root was found in its side's table.  A found root is evaluated
+            // once more unless nn_cache holds the position (mcts.py:359-371; the cache belongs to the side's MCTS object).
+            if (sync_games_d2h(sp) != 0) return -1;
+            bool any = false;
+            for (size_t k = 0; k < ids.size(); ++k) {
+                if (slots[k] > -2) continue;
+                GameDev& g = sp->hg[ids[k]];
+                const uint64_t salt = (g.net_id & 1) ? 0x9E3779B97F4A7C15ull : 0ull;
+                const uint64_t gsalt = (uint64_t)(uint32_t)sp->games[ids[k]].game_index * 0xD6E8FEB86659FD93ull;
+                g.reinfer = (g.root_found && nn_cache_miss(sp, tkey(g.root_pos) ^ salt ^ gsalt)) ? 1 : 0;
+                any = any || g.reinfer;
+            }
+            if (any && sync_games_h2d(sp) != 0) return -1;
+        }
     }
     return 0;
 }
@@ -578,13 +596,16 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->d.samples = dalloc<Sample>(sp, (size_t)sp->G * LS);
     sp->d.paths = dalloc<int>(sp, (size_t)sp->G * LS * M0_MAX_DEPTH);
     sp->d.leaf_moves = dalloc<uint16_t>(sp, (size_t)sp->G * LS * M0_MAX_CHILDREN);
+    sp->d.tt_sides = 1;
     if (cfg->tt_merge) {
         int tc = 1024;
         while (tc < 2 * sp->cap) tc <<= 1;
         sp->d.tt_cap = tc;
+        // match engine: one table per side, kept for the whole game (the reference keeps one MCTS object per side, arena.py:157-158)
+        sp->d.tt_sides = sp->cfg.arena_mode ? 2 : 1;
         sp->d.epaths = dalloc<int>(sp, (size_t)sp->G * LS * M0_MAX_DEPTH);
-        sp->d.tt_keys = dalloc<uint64_t>(sp, (size_t)sp->G * tc);
-        sp->d.tt_nodes = dalloc<int>(sp, (size_t)sp->G * tc);
+        sp->d.tt_keys = dalloc<uint64_t>(sp, (size_t)sp->G * sp->d.tt_sides * tc);
+        sp->d.tt_nodes = dalloc<int>(sp, (size_t)sp->G * sp->d.tt_sides * tc);
         if (!sp->d.epaths || !sp->d.tt_keys || !sp->d.tt_nodes) {
             m0_set_error("hipMalloc failed for the position tables (tt_merge): lower concurrent_games or arena_nodes");
             m0_selfplay_destroy(sp);

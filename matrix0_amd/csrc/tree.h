@@ -58,6 +58,9 @@ struct GameDev {
     uint64_t evals;           // network evaluations consumed by this game (counted by the engine)
     int net_id;               // arena: which network evaluates this game's current search (0 / 1); self-play: 0
     int reinfer;              // evaluate the (reused) root once more at the first select of this search (mcts.py:359-371)
+    // match engine with compat.tt_merge (TreeDev::tt_sides == 2): arena half s and table s belong to side s for the WHOLE game
+    int side_next[2];         // bump allocator of each side's half while the other side searches
+    int root_found;           // advance_kernel: this search's root was found in the side's table (mcts.py:343, 359-371)
 };
 
 struct Sample {
@@ -103,7 +106,9 @@ struct TreeDev {
     int* epaths;              // tt_merge: [G][L+1][M0_MAX_DEPTH] the edge children chosen at each level (virtual-loss owners)
     uint64_t* tt_keys;        // tt_merge: [G][tt_cap] position keys, 0 = empty (open addressing, linear probing)
     int* tt_nodes;            // tt_merge: [G][tt_cap] node registered LAST under the key
-    int tt_cap;               // entries per game, a power of two
+    int tt_cap;               // entries per table, a power of two
+    int tt_sides;             // tables per game: 1, or 2 in a match engine with compat.tt_merge (one per side, kept all game:
+                              // the reference keeps one MCTS object, hence one table, per side -- arena.py:157-158)
     uint16_t* leaf_moves;     // [G][L+1][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order
     uint64_t* hist;           // [G][M0_HIST_CAP]
     RootResult* results;      // [G]
@@ -118,6 +123,8 @@ struct TreeDev {
 
 hipError_t launch_select(const TreeDev& d, const TreeCfg& c, hipStream_t st);
 hipError_t launch_expand(const TreeDev& d, const TreeCfg& c, hipStream_t st);
+// child_slots: >= 0 keep that child's subtree; -1 fresh tree (and an empty table); tt_sides == 2 only: -2 next search of a
+// game (root looked up in the side's table), -3 first search of a game (both tables cleared first)
 hipError_t launch_advance(const TreeDev& d, const int* game_ids_dev, const int* child_slots_dev, int count, hipStream_t st);
 
 // test hooks: position-wise encode / legal move / index kernels (encoding.py on device)

@@ -304,6 +304,11 @@ __device__ void apply_dirichlet(const Arena& A, int root, GameDev* gd, const Tre
     __syncthreads();
 }
 
+// table of game g (of its side gd->arena in a match engine with per-side tables)
+__device__ __forceinline__ size_t tt_table_of(const TreeDev& d, int g, const GameDev* gd) {
+    return ((size_t)g * d.tt_sides + (d.tt_sides == 2 ? gd->arena : 0)) * (size_t)d.tt_cap;
+}
+
 __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     __shared__ uint64_t pkey[M0_MAX_DEPTH];
     __shared__ uint8_t pirr[M0_MAX_DEPTH];
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     Sample* S = d.samples + (size_t)g * (d.L + 1);
     int* P = d.paths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH;
     int* EP = c.tt_merge ? d.epaths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH : nullptr;
-    const uint64_t* TK = c.tt_merge ? d.tt_keys + (size_t)g * d.tt_cap : nullptr;
-    const int* TN = c.tt_merge ? d.tt_nodes + (size_t)g * d.tt_cap : nullptr;
+    const uint64_t* TK = c.tt_merge ? d.tt_keys + tt_table_of(d, g, gd) : nullptr;
+    const int* TN = c.tt_merge ? d.tt_nodes + tt_table_of(d, g, gd) : nullptr;
     // mcts.py:359-371: a root taken over from the previous search is evaluated once more (value only)
     auto emit_reinfer = [&](int at) {
         int row = 0;
@@ -506,7 +511,7 @@ struct ExpandScratch {          // workgroup-shared staging of one expansion (ra
 
 __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg& c, int leaf, const Pos& pos,
                             const float* lg, const uint16_t* smoves, int n, int lane, bool is_root, ExpandScratch* X,
-                            uint64_t* TK, int* TN, int tt_cap) {
+                            uint64_t* TK, int* TN, int tt_cap, bool reg_children) {
     // legal moves of the leaf come from select (same position, same order): no second move generation
     if (n <= 0) return true;
     // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
@@ -678,14 +683,16 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
             A.cbase[ci] = -1; A.nch[ci] = -1; A.mv[ci] = mvv[k]; A.midx[ci] = (uint16_t)idx[k];
             // _register_children_in_tt (mcts.py:1330-1346): every child of an expanded NON-root node goes into the table
             // under the key of the position it leads to (run() registers only the fresh root itself, mcts.py:344-358)
-            if (TK && !is_root) {
+            // A root that run() FOUND in the table and had to expand registers its children like any other node
+            // (mcts.py:398-413): reg_children is false only for the brand-new root, which is registered itself instead.
+            if (TK && reg_children) {
                 Pos q = pos;
                 make_move(q, mvv[k]);
                 tt_insert(TK, TN, tt_cap, tt_key_of(q), ci);
             }
         }
     }
-    if (TK && is_root && lane == 0) tt_insert(TK, TN, tt_cap, tt_key_of(pos), leaf);
+    if (TK && !reg_children && lane == 0) tt_insert(TK, TN, tt_cap, tt_key_of(pos), leaf);
     if (lane == 0) { A.cbase[leaf] = cb; A.nch[leaf] = (int16_t)nkeep; gd->next = cb + nkeep; }
     __syncthreads();
     return true;
@@ -696,8 +703,8 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
     const int g = blockIdx.x, lane = threadIdx.x;
     GameDev* gd = &d.games[g];
     if (!gd->active) return;
-    uint64_t* TK = c.tt_merge ? d.tt_keys + (size_t)g * d.tt_cap : nullptr;
-    int* TN = c.tt_merge ? d.tt_nodes + (size_t)g * d.tt_cap : nullptr;
+    uint64_t* TK = c.tt_merge ? d.tt_keys + tt_table_of(d, g, gd) : nullptr;
+    int* TN = c.tt_merge ? d.tt_nodes + tt_table_of(d, g, gd) : nullptr;
     const uint16_t* LM = d.leaf_moves + (size_t)g * (d.L + 1) * M0_MAX_CHILDREN;
     const int ns = gd->nsamples;
     if (ns <= 0) return;
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
             if (A.nch[leaf] < 0) {
                 const Pos pos = S[s].pos;
                 expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane,
-                            kind == 2, &X, TK, TN, d.tt_cap);
+                            kind == 2, &X, TK, TN, d.tt_cap, !(kind == 2 && gd->root_fresh));
             }
             ++evals;
             if (kind == 1) {
@@ -783,11 +790,42 @@ __global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_
     if (j >= count) return;
     const int g = game_ids[j], slot = child_slots[j];
     GameDev* gd = &d.games[g];
+    if (slot <= -2) {
+        // match engine with per-side tables (tt_sides == 2): side = the network that searches now.  Nothing is compacted or
+        // cleared between the searches of a game; the root is whatever node the side's table holds for the position
+        // (MCTS.run: root = self._tt_get(key), mcts.py:343), else a new node.
+        const int s = gd->net_id & 1;
+        const int prev_side = gd->arena & 1, prev_next = gd->next;
+        if (slot == -3) {
+            uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + (size_t)g * 2 * d.tt_cap);
+            for (int i = lane; i < d.tt_cap; i += 64) tk[i] = make_uint4(0, 0, 0, 0);       // both tables: 2 * tt_cap keys
+        }
+        __syncthreads();
+        int nxt = slot == -3 ? 0 : (s == prev_side ? prev_next : gd->side_next[s]);
+        const Arena A = arena_of(d.t, g, s);
+        const uint64_t* TK = d.tt_keys + ((size_t)g * 2 + s) * d.tt_cap;
+        const int* TN = d.tt_nodes + ((size_t)g * 2 + s) * d.tt_cap;
+        int node = slot == -3 ? -1 : tt_lookup(TK, TN, d.tt_cap, tt_key_of(gd->root_pos), lane);
+        const bool found = node >= 0;
+        if (lane == 0) {
+            if (slot != -3) gd->side_next[prev_side] = prev_next;
+            else { gd->side_next[0] = 0; gd->side_next[1] = 0; }
+            if (!found) {
+                node = nxt < d.t.cap ? nxt : d.t.cap - 1;
+                A.prior[node] = 0.0; A.w[node] = 0.0; A.q[node] = 0.0; A.n[node] = 0; A.vl[node] = 0; A.cbase[node] = -1; A.nch[node] = -1;
+                A.mv[node] = 0; A.midx[node] = 0;
+                nxt = node + 1;
+            }
+            gd->arena = s; gd->root = node; gd->next = nxt; gd->overflow = nxt >= d.t.cap ? 1 : 0;
+            gd->root_fresh = found ? 0 : 1; gd->root_found = found ? 1 : 0;
+        }
+        return;
+    }
     if (slot < 0) {
         const Arena D = arena_of(d.t, g, 0);
         if (d.tt_keys) {                             // a fresh root starts with an empty position table
-            uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + (size_t)g * d.tt_cap);
-            for (int i = lane; i < d.tt_cap / 2; i += 64) tk[i] = make_uint4(0, 0, 0, 0);
+            uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + (size_t)g * d.tt_sides * d.tt_cap);
+            for (int i = lane; i < d.tt_sides * d.tt_cap / 2; i += 64) tk[i] = make_uint4(0, 0, 0, 0);
         }
         if (lane == 0) {
             D.prior[0] = 0.0; D.w[0] = 0.0; D.q[0] = 0.0; D.n[0] = 0; D.vl[0] = 0; D.cbase[0] = -1; D.nch[0] = -1;

@@ -79,18 +79,21 @@ from tests.golden_ref import load_json, uci as _uci      # noqa: E402
 ARENA = load_json("ref_arena.json.gz")
 
 
-@pytest.mark.parametrize("gi", [i for i, g in enumerate(ARENA["games"]) if g["tt"] == "off"])
+@pytest.mark.parametrize("gi", range(len(ARENA["games"])))
 def test_match_engine_plays_the_reference_arena_game(gi):
     """m0_arena_create_ext + the two-evaluator step of the C-ABI against the game the reference's arena loop played
-    (arena.py:59-126; one MCTS object per side, table patched out): the side to move's evaluator at every ply, visit counts of
+    (arena.py:59-126; one MCTS object per side; its table patched out, and untouched): the side to move's evaluator at every ply, visit counts of
     every search (as the float32 policy target n / total), root values, the sampled / most visited move, adjudication and
     length cap, the result, and the number of evaluations each network was asked for."""
     from matrix0_amd import engine as eng
     g = ARENA["games"][gi]
     cfg_dict = {"seed": ARENA["seed"], "mcts": dict(g["mcts"]), "draw": dict(g["draw"]),
                 "selfplay": {"num_simulations": g["sims"], "max_game_len": g["max_moves"], "opening_random_plies": 0}}
+    # tt = "on": the untouched reference, one table per side for the whole game = the match engine with compat.tt_merge (the
+    # node arena must then hold everything a side creates in a game)
     cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=1, total_games=1, first_game_index=g["uid"],
-                                     virtual_loss_active=False, record_games=True)
+                                     virtual_loss_active=False, record_games=True, compat={"tt_merge": g["tt"] == "on"},
+                                     arena_nodes=400000 if g["tt"] == "on" else 0)
     cfg.arena_temp, cfg.arena_temp_plies = float(g["temp"]), int(g["temp_plies"])
     e = eng.ArenaExtEngine(cfg)
     na, nb = HashNet(**g["net_a"]), HashNet(**g["net_b"])
