@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=4, help="torch threads per CPU-baseline worker process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval-cache", action="store_true",
+                    help="switch the per-game evaluation cache off (every leaf goes through the network, repeated positions too)")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
                          "+3..4 %% games/s, but per-launch kernel timings then include the other stream's kernels, so the "
@@ -234,13 +236,15 @@ def main():
     first_index = rank * (1 << 24)
     cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
                                      first_game_index=first_index, leaves_per_step=args.leaves,
-                                     virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
+                                     virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False,
+                                     eval_cache=not args.no_eval_cache)
     if args.streams > 1:
         made = [be]
         e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
                              cfg_dict, streams=args.streams, concurrent_games=args.games, total_games=0,
                              first_game_index=first_index, leaves_per_step=args.leaves,
-                             virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False)
+                             virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False,
+                             eval_cache=not args.no_eval_cache)
     else:
         e = eng.SelfplayEngine(be, cfg)
 
@@ -277,11 +281,12 @@ def main():
     conv_ms, conv_flop, conv_launches = be.profile_get(reset=True)
     be.profile_enable(False)
 
-    d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total")}
+    d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total",
+                                    "evals_cached")}
     counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
-                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed], dtype=np.float64)
+                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed, d["evals_cached"]], dtype=np.float64)
     dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
-    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all = [float(x) for x in tot]
+    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all, cached = [float(x) for x in tot]
     passes = max(1.0, passes_all / args.gpus)           # passes per rank in the timed region
 
     if rank == 0:
@@ -321,6 +326,12 @@ def main():
                        "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
+            # every simulation is played; a leaf whose position this game evaluated before (a transposition inside the search, a
+            # position of a discarded subtree) is expanded from the stored value + legal logits instead of a second forward --
+            # the reference's position table does not evaluate a transposed node twice either (mcts.py:919).  Games are
+            # bit-identical with the cache off (tests/test_eval_cache_gpu.py); `evals_per_s` counts network evaluations only.
+            "eval_cache": {"enabled": not args.no_eval_cache, "evaluations_from_cache": int(cached),
+                           "share_of_leaf_evaluations": cached / max(1.0, cached + evals)},
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "passes_per_step": passes / max(1, args.steps), "ms_per_pass": dt_max * 1e3 / passes,
             # the timed region is the friendliest regime: all resident searches are in step, so every pass is a full batch and a

@@ -176,6 +176,12 @@ typedef struct m0_selfplay_cfg {
     int max_children;             /* MCTS._prune_children (mcts.py:806-826): keep the top-K children by prior; 0 = off */
     double min_child_prior;       /* ... after dropping children with prior < this; 0 = off */
     int root_reinfer;             /* 1 = re-evaluate a reused root as mcts.py:359-371 does (nn_cache of 10 000 positions) */
+    /* per-game evaluation cache (csrc/tree.h EvalCache): a leaf whose position was evaluated before -- a transposition inside
+     * the search, a position of a discarded subtree -- is expanded from the stored value + legal logits instead of going
+     * through the network again.  Games are unchanged (the forward is bitwise batch invariant on the 320-wide path).  Active
+     * only with legal_softmax = 1 and without tt_merge / raw_legal_priors.  0 = off. */
+    int eval_cache;
+    int eval_cache_entries;       /* entries per game (rounded up to a power of two, 4-way sets); 0 = 16384 */
 } m0_selfplay_cfg;
 
 typedef struct m0_selfplay m0_selfplay;
@@ -185,6 +191,7 @@ typedef struct m0_selfplay_stats {
     double ms_total, ms_net, ms_tree, ms_host;   /* accumulated wall (host) and device (HIP events) times */
     uint64_t arena_overflows;
     uint64_t ssl_dropped;         /* finished games emitted WITHOUT ssl_* targets because their staging buffers could not grow */
+    uint64_t evals_cached;        /* leaf evaluations served by the evaluation cache (not counted in `evals`) */
     int active_games;
 } m0_selfplay_stats;
 

@@ -122,6 +122,8 @@ void fill_tree_cfg(const m0_selfplay_cfg& c, TreeCfg& t) {
     t.virtual_loss_active = c.virtual_loss_active; t.leaves_per_step = c.inference_batch_size;
     t.tt_merge = c.tt_merge; t.raw_legal_priors = c.raw_legal_priors; t.max_children = c.max_children;
     t.min_child_prior = c.min_child_prior;
+    // the cached payload is the LEGAL logits: only the legal-softmax expansion can be served from it
+    t.eval_cache = (c.eval_cache && c.legal_softmax && !c.raw_legal_priors && !c.tt_merge) ? 1 : 0;
 }
 
 // mcts.py:359-371: a root that run() finds already in its table is evaluated again unless the position sits in nn_cache
@@ -478,6 +480,11 @@ int step_back(m0_selfplay* sp, int rows, double t0, std::string& err) {
     const double t1 = now_ms();
     // host: finished searches -> moves, game ends, restarts
     bool any = false;
+    if (sp->tc.eval_cache) {
+        uint64_t h = 0;
+        for (int s = 0; s < sp->G; ++s) h += sp->hg[s].cache_hits;
+        sp->stats.evals_cached = h;
+    }
     for (int s = 0; s < sp->G; ++s) {
         if (!sp->hg[s].active) continue;
         const int delta = sp->hg[s].sims_done - sp->prev_done[s];
@@ -608,6 +615,22 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
         sp->d.tt_nodes = dalloc<int>(sp, (size_t)sp->G * sp->d.tt_sides * tc);
         if (!sp->d.epaths || !sp->d.tt_keys || !sp->d.tt_nodes) {
             m0_set_error("hipMalloc failed for the position tables (tt_merge): lower concurrent_games or arena_nodes");
+            m0_selfplay_destroy(sp);
+            return nullptr;
+        }
+    }
+    if (sp->tc.eval_cache) {
+        int entries = cfg->eval_cache_entries > 0 ? cfg->eval_cache_entries : 16384;
+        int sets = 64;
+        while (sets * 4 < entries) sets <<= 1;
+        EvalCache& ec = sp->d.ec;
+        ec.sets = sets;
+        ec.keys = dalloc<uint64_t>(sp, (size_t)sp->G * sets * 4);
+        ec.stamps = dalloc<uint32_t>(sp, (size_t)sp->G * sets * 4);
+        ec.payload = dalloc<float>(sp, (size_t)sp->G * sets * 4 * M0_EC_WORDS);
+        ec.hit_stage = dalloc<float>(sp, (size_t)sp->G * LS * M0_EC_WORDS);
+        if (!ec.keys || !ec.stamps || !ec.payload || !ec.hit_stage) {
+            m0_set_error("hipMalloc failed for the evaluation cache: lower eval_cache_entries or concurrent_games");
             m0_selfplay_destroy(sp);
             return nullptr;
         }

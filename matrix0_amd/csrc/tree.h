@@ -32,6 +32,25 @@ struct TreeCfg {              // MCTSConfig fields the kernels read (mcts.py:61-
     int raw_legal_priors;     // mcts.py:227-256 for non-root expansions
     int max_children;         // mcts.py:806-826
     double min_child_prior;
+    int eval_cache;           // 1: leaf evaluations are looked up in / stored to the game's evaluation cache (EvalCache) and a leaf
+                              //    reached twice in one pass shares one batch row
+};
+
+// Per-game evaluation cache: what the network said about a position (value + the logits of its legal moves, in generation
+// order), keyed by everything the network input and the expansion depend on (pieces, turn, castling rights, legal
+// en-passant square, the two move counters as the planes encode them).  A repeated position -- a transposition inside the
+// search, a position whose node was dropped with a discarded subtree -- is expanded from the cache instead of costing a
+// network evaluation.  Same role as the reference's position table, which never evaluates a transposed node twice
+// (mcts.py:919), and its nn_cache (mcts.py:44-59); results are unchanged because the 320-wide forward is bitwise batch
+// invariant (a fresh evaluation would return the very same numbers).  4-way set associative, least recently used way replaced.
+#define M0_EC_MAXLEGAL 64     // positions with more legal moves are not cached
+#define M0_EC_WORDS 66        // payload floats per entry: value, nlegal (as int bits), 64 logits
+struct EvalCache {
+    uint64_t* keys;           // [G][sets * 4], 0 = empty
+    uint32_t* stamps;         // [G][sets * 4] last use (per-game clock)
+    float* payload;           // [G][sets * 4][M0_EC_WORDS]
+    float* hit_stage;         // [G][L + 1][M0_EC_WORDS] payload of this pass's hits (an insert of the same pass may evict the entry)
+    int sets;                 // per game, a power of two; 0 = cache off
 };
 
 // Per-game control block (host writes between steps, kernels update counters).
@@ -59,6 +78,8 @@ struct GameDev {
     int net_id;               // arena: which network evaluates this game's current search (0 / 1); self-play: 0
     int reinfer;              // evaluate the (reused) root once more at the first select of this search (mcts.py:359-371)
     // match engine with compat.tt_merge (TreeDev::tt_sides == 2): arena half s and table s belong to side s for the WHOLE game
+    uint64_t cache_hits;      // leaf evaluations served by the evaluation cache
+    uint32_t cache_clock;
     int side_next[2];         // bump allocator of each side's half while the other side searches
     int root_found;           // advance_kernel: this search's root was found in the side's table (mcts.py:343, 359-371)
 };
@@ -66,7 +87,9 @@ struct GameDev {
 struct Sample {
     m0::Pos pos;              // leaf position
     int kind;                 // 0 none, 1 eval+backup, 2 root init (expand only), 3 terminal (already backed up),
-                              // 4 root value only (re-evaluation of a reused root)
+                              // 4 root value only (re-evaluation of a reused root), 5 eval served by the evaluation cache,
+                              // 6 the same leaf as an earlier sample of this pass (shares its batch row)
+    uint64_t ckey;            // evaluation-cache key of the leaf (0: not cacheable / cache off)
     int leaf;
     int depth;                // path has depth+1 nodes
     int row;                  // network batch row
@@ -107,6 +130,7 @@ struct TreeDev {
     uint64_t* tt_keys;        // tt_merge: [G][tt_cap] position keys, 0 = empty (open addressing, linear probing)
     int* tt_nodes;            // tt_merge: [G][tt_cap] node registered LAST under the key
     int tt_cap;               // entries per table, a power of two
+    EvalCache ec;
     int tt_sides;             // tables per game: 1, or 2 in a match engine with compat.tt_merge (one per side, kept all game:
                               // the reference keeps one MCTS object, hence one table, per side -- arena.py:157-158)
     uint16_t* leaf_moves;     // [G][L+1][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         if (lane == 0) row = atomicAdd(d.row_counter + gd->net_id, 1) + gd->net_id * d.net_row_base;
         row = __shfl(row, 0);
         if (lane == 0) {
-            Sample s; s.pos = gd->root_pos; s.kind = 4; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = 0;
+            Sample s; s.pos = gd->root_pos; s.kind = 4; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = 0; s.ckey = 0;
             S[at] = s; gd->reinfer = 0;
         }
         encode_nhwc(gd->root_pos, d.x0 + (size_t)row * 64 * 32, lane);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         const int nl = gen_legal_wave(rp, smoves, spseudo, lane);
         for (int i = lane; i < nl; i += 64) LM[i] = smoves[i];
         if (lane == 0) {
-            Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = nl;
+            Sample s; s.pos = rp; s.kind = 2; s.leaf = root; s.depth = 0; s.row = row; s.nlegal = nl; s.ckey = 0;
             S[0] = s; P[0] = root; gd->nsamples = reinfer ? 2 : 1;
         }
         encode_nhwc(rp, d.x0 + (size_t)row * 64 * 32, lane);
@@ -469,15 +469,45 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             if (cnt >= 5) { term = true; tv = c.draw_penalty; }
         }
         int row = -1;
-        if (!term) {
+        uint64_t ckey = 0;
+        bool cached = false;
+        if (!term && c.eval_cache && d.ec.sets > 0 && nlegal <= M0_EC_MAXLEGAL) {
+            // the key covers what the planes and the expansion depend on: tkey (pieces, turn, cleaned castling rights, legal ep)
+            // and the two counters as plane_consts clips them
+            const uint64_t hm = pos.halfmove < 99 ? pos.halfmove : 99, fm = pos.fullmove < 199 ? pos.fullmove : 199;
+            ckey = mix64(tkey(pos) ^ ((hm << 8 | fm) * 0x9E3779B97F4A7C15ull)) | 1ull;
+            const size_t eb = ((size_t)g * d.ec.sets + (size_t)((ckey >> 1) & (uint64_t)(d.ec.sets - 1))) * 4;
+            const uint64_t k = lane < 4 ? d.ec.keys[eb + lane] : 0ull;
+            const unsigned long long hit = __ballot(lane < 4 && k == ckey);
+            if (hit) {
+                const int way = __builtin_ctzll(hit);
+                const float* src = d.ec.payload + (eb + way) * M0_EC_WORDS;
+                float* dst = d.ec.hit_stage + ((size_t)g * (d.L + 1) + s) * M0_EC_WORDS;
+                for (int i = lane; i < M0_EC_WORDS; i += 64) dst[i] = src[i];
+                // the legal-move count must agree (it is part of what the key stands for): a mismatch = a key collision
+                cached = __float_as_int(src[1]) == nlegal;
+                if (cached && lane == 0) { d.ec.stamps[eb + way] = ++gd->cache_clock; }
+            }
+        }
+        // The same unexpanded node reached again in this pass (a batch of 96 descents over a young tree lands on the same leaf
+        // many times; the virtual loss only spreads them): it shares the batch row of its first occurrence instead of being
+        // evaluated twice in one forward.  The pending row sits in the node's child-base field, which means nothing until the
+        // node is expanded: cbase <= -2  <=>  row -(cbase + 2) of this pass (expand_kernel resets it).
+        bool shared = false;
+        if (!term && !cached && c.eval_cache) {
+            const int pend = A.cbase[node];
+            if (A.nch[node] < 0 && pend <= -2) { shared = true; row = -(pend + 2); }
+        }
+        if (!term && !cached && !shared) {
             if (lane == 0) row = atomicAdd(d.row_counter + gd->net_id, 1) + gd->net_id * d.net_row_base;
             row = __shfl(row, 0);
             encode_nhwc(pos, d.x0 + (size_t)row * 64 * 32, lane);
+            if (c.eval_cache && lane == 0 && A.nch[node] < 0) A.cbase[node] = -(row + 2);
         }
-        if (!term) for (int i = lane; i < nlegal; i += 64) LM[(size_t)s * M0_MAX_CHILDREN + i] = smoves[i];
+        if (!term && !shared) for (int i = lane; i < nlegal; i += 64) LM[(size_t)s * M0_MAX_CHILDREN + i] = smoves[i];
         if (lane == 0) {
-            Sample smp; smp.pos = pos; smp.kind = term ? 3 : 1; smp.leaf = node; smp.depth = depth; smp.row = row;
-            smp.nlegal = nlegal;
+            Sample smp; smp.pos = pos; smp.kind = term ? 3 : (cached ? 5 : (shared ? 6 : 1)); smp.leaf = node; smp.depth = depth; smp.row = row;
+            smp.nlegal = nlegal; smp.ckey = cached ? 0ull : ckey;
             S[s] = smp;
         }
         __syncthreads();                                 // path[] (lane 0) before the wave reads it
@@ -507,17 +537,19 @@ struct ExpandScratch {          // workgroup-shared staging of one expansion (ra
     uint16_t idx[M0_MAX_CHILDREN];
     uint8_t keep[M0_MAX_CHILDREN];
     float total;
+    int bad;                    // the logits of the last expansion held a non-finite value (not cached)
 };
 
 __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg& c, int leaf, const Pos& pos,
                             const float* lg, const uint16_t* smoves, int n, int lane, bool is_root, ExpandScratch* X,
-                            uint64_t* TK, int* TN, int tt_cap, bool reg_children) {
+                            uint64_t* TK, int* TN, int tt_cap, bool reg_children, const float* cl = nullptr, float* cw = nullptr) {
     // legal moves of the leaf come from select (same position, same order): no second move generation
+    // cl: the legal moves' logits from the evaluation cache (lg is then null); cw: cache payload to fill with them
     if (n <= 0) return true;
     // non-finite logits anywhere -> uniform priors (mcts.py:147-149)
     // (16-byte loads, all of a lane's 19 in flight together: one memory latency instead of 73 dependent-looking ones)
     bool bad = false;
-    {
+    if (!cl) {
         const uint4* lg4 = reinterpret_cast<const uint4*>(lg);         // 4672 floats = 1168 x 16 B, rows are 16-byte aligned
         uint4 v[19];
 #pragma unroll
@@ -531,6 +563,7 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
         bad = acc != 0;
     }
     bad = __any(bad);
+    if (lane == 0) X->bad = bad ? 1 : 0;
     float pr[4];
     int idx[4];
     Move mvv[4];
@@ -570,7 +603,12 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
             cnt = n;
             float l[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int i = lane + 64 * k; l[k] = i < n ? lg[idx[k]] : -3.0e38f; mx = fmaxf(mx, l[k]); }
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k;
+                l[k] = i < n ? (cl ? cl[i] : lg[idx[k]]) : -3.0e38f;
+                mx = fmaxf(mx, l[k]);
+                if (cw && i < n && i < M0_EC_MAXLEGAL) cw[2 + i] = l[k];
+            }
             mx = wave_max_f(mx);
             double e[4], sum = 0.0;
 #pragma unroll
@@ -712,18 +750,65 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
     const Sample* S = d.samples + (size_t)g * (d.L + 1);
     const int* P = d.paths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH;
     int sims = 0;
-    uint64_t evals = 0;
+    uint64_t evals = 0, hits = 0;
     for (int s = 0; s < ns; ++s) {
         const int kind = S[s].kind;
         const int* path = P + (size_t)s * M0_MAX_DEPTH;
-        if (kind == 1 || kind == 2) {
+        if (kind == 6) {                         // same leaf as an earlier sample of this pass: its row's value, no second expansion
+            const float v = d.values[S[s].row];
+            backprop(A, path, S[s].depth, (double)v, lane, c.tt_merge != 0);
+            ++sims; ++hits;
+            __syncthreads();
+        } else if (kind == 5) {                  // evaluation served by the cache: expand from the staged payload
+            const int leaf = S[s].leaf, depth = S[s].depth;
+            const float* pay = d.ec.hit_stage + ((size_t)g * (d.L + 1) + s) * M0_EC_WORDS;
+            const float v = pay[0];
+            if (A.nch[leaf] < 0) {
+                const Pos pos = S[s].pos;
+                expand_node(A, d.t.cap, gd, c, leaf, pos, nullptr, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane,
+                            false, &X, TK, TN, d.tt_cap, true, pay + 2, nullptr);
+            }
+            backprop(A, path, depth, (double)v, lane, c.tt_merge != 0);
+            ++sims; ++hits;
+            __syncthreads();
+        } else if (kind == 1 || kind == 2) {
             const int leaf = S[s].leaf, depth = S[s].depth, row = S[s].row;
             const float* lg = d.logits + (size_t)row * 4672;
             const float v = d.values[row];
             if (A.nch[leaf] < 0) {
                 const Pos pos = S[s].pos;
-                expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane,
-                            kind == 2, &X, TK, TN, d.tt_cap, !(kind == 2 && gd->root_fresh));
+                // a cacheable leaf (kind 1, key set by select): its evaluation goes into the least recently used way of its set
+                float* cw = nullptr;
+                size_t ce = 0;
+                const uint64_t ckey = kind == 1 ? S[s].ckey : 0ull;
+                if (ckey != 0 && isfinite(v)) {
+                    const size_t eb = ((size_t)g * d.ec.sets + (size_t)((ckey >> 1) & (uint64_t)(d.ec.sets - 1))) * 4;
+                    const uint64_t k = lane < 4 ? d.ec.keys[eb + lane] : 0ull;
+                    const uint32_t st = lane < 4 ? d.ec.stamps[eb + lane] : 0xffffffffu;
+                    const unsigned long long same = __ballot(lane < 4 && k == ckey), empty = __ballot(lane < 4 && k == 0ull);
+                    int way;
+                    if (same) way = __builtin_ctzll(same);
+                    else if (empty) way = __builtin_ctzll(empty);
+                    else {
+                        uint32_t m = st; int w = lane;
+                        for (int o = 2; o > 0; o >>= 1) { const uint32_t om = __shfl_xor(m, o); const int ow = __shfl_xor(w, o); if (om < m || (om == m && ow < w)) { m = om; w = ow; } }
+                        way = __shfl(w, 0);
+                    }
+                    ce = eb + way;
+                    cw = d.ec.payload + ce * M0_EC_WORDS;
+                    if (lane == 0) d.ec.keys[ce] = 0ull;            // invalid while it is being rewritten
+                }
+                const bool ok = expand_node(A, d.t.cap, gd, c, leaf, pos, lg, LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane,
+                                            kind == 2, &X, TK, TN, d.tt_cap, !(kind == 2 && gd->root_fresh), nullptr, cw);
+                // an expansion that did not happen (node arena exhausted) must not leave the pending-row mark behind
+                if (c.eval_cache && kind == 1 && lane == 0 && A.nch[leaf] < 0) A.cbase[leaf] = -1;
+                if (cw && lane == 0) {
+                    if (ok && !X.bad) {
+                        cw[0] = v; cw[1] = __int_as_float(S[s].nlegal);
+                        __threadfence_block();
+                        d.ec.keys[ce] = ckey; d.ec.stamps[ce] = ++gd->cache_clock;
+                    }
+                }
             }
             ++evals;
             if (kind == 1) {
@@ -752,7 +837,7 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
     if (c.virtual_loss_active) {
         for (int s = lane; s < ns; s += 64) {
             const int kind = S[s].kind;
-            if (kind == 1 || kind == 3) {
+            if (kind == 1 || kind == 3 || kind == 5 || kind == 6) {
                 // the in-flight counts sit on the EDGE children (tt_merge: the walk itself may have continued elsewhere)
                 const int* path = (c.tt_merge ? d.epaths + (size_t)g * (d.L + 1) * M0_MAX_DEPTH : P) + (size_t)s * M0_MAX_DEPTH;
                 for (int dd = 1; dd <= S[s].depth; ++dd) atomicSub(&A.vl[path[dd]], 1);
@@ -766,6 +851,7 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
     if (lane == 0) {
         gd->sims_done = done;
         gd->evals += evals;
+        gd->cache_hits += hits;
         gd->finished = fin ? 1 : 0;
         gd->root_n = A.n[root];
         gd->root_q = A.q[root];

@@ -30,14 +30,14 @@ class SelfplayCfg(C.Structure):
         ("seed", c_u64), ("virtual_loss_active", c_int), ("ssl_in_forward", c_int), ("ssl_targets", c_int), ("record_games", c_int),
         ("arena_mode", c_int), ("arena_temp", c_double), ("arena_temp_plies", c_int),
         ("fresh_tree_per_move", c_int), ("tt_merge", c_int), ("raw_legal_priors", c_int), ("max_children", c_int),
-        ("min_child_prior", c_double), ("root_reinfer", c_int),
+        ("min_child_prior", c_double), ("root_reinfer", c_int), ("eval_cache", c_int), ("eval_cache_entries", c_int),
     ]
 
 
 class SelfplayStats(C.Structure):
     _fields_ = [("steps", c_u64), ("evals", c_u64), ("sims", c_u64), ("plies", c_u64), ("games_finished", c_u64),
                 ("games_started", c_u64), ("ms_total", c_double), ("ms_net", c_double), ("ms_tree", c_double),
-                ("ms_host", c_double), ("arena_overflows", c_u64), ("ssl_dropped", c_u64), ("active_games", c_int)]
+                ("ms_host", c_double), ("arena_overflows", c_u64), ("ssl_dropped", c_u64), ("evals_cached", c_u64), ("active_games", c_int)]
 
 
 class GameRecord(C.Structure):
@@ -105,7 +105,7 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
                            seed: Optional[int] = None, leaves_per_step: Optional[int] = None,
                            virtual_loss_active: bool = True, ssl_in_forward: bool = False,
                            record_games: bool = True, arena_nodes: int = 0, ssl_targets: bool = False,
-                           compat: Optional[dict] = None) -> SelfplayCfg:
+                           compat: Optional[dict] = None, eval_cache: Optional[bool] = None) -> SelfplayCfg:
     """Merge config.yaml's `mcts`, `selfplay` and draw sections exactly as selfplay_worker does
     (azchess/selfplay/internal.py:192-199, 269-304) into the engine's C struct.  MCTSConfig
     defaults are the dataclass defaults of azchess/mcts.py:61-107."""
@@ -183,6 +183,10 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     c.tt_merge = int(bool(cp.get("tt_merge", False)))
     c.raw_legal_priors = int(bool(cp.get("raw_legal_priors", False)))
     c.root_reinfer = int(bool(cp.get("root_reinfer", False)))
+    # evaluation cache: `engine.eval_cache` in config.yaml or the keyword; off unless asked for (parity tests count evaluations)
+    ecfg = cfg.get("engine", {}) or {}
+    c.eval_cache = int(bool(ecfg.get("eval_cache", False) if eval_cache is None else eval_cache))
+    c.eval_cache_entries = int(ecfg.get("eval_cache_entries", 0) or 0)
     return c
 
 

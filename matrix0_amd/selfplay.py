@@ -99,7 +99,9 @@ def selfplay_worker(proc_id: int, cfg_dict: dict, ckpt_path: Optional[str], game
     concurrent = int(eng_cfg.get("concurrent_games", min(max(1, games), 256)))
     eng_kw = dict(seed=base_seed, leaves_per_step=eng_cfg.get("leaves_per_step"),          # None: mcts.inference_batch_size, as the reference
                   virtual_loss_active=bool(eng_cfg.get("virtual_loss_active", True)), record_games=True,
-                  ssl_targets=bool(ssl_tasks), arena_nodes=int(eng_cfg.get("arena_nodes", 0) or 0))
+                  ssl_targets=bool(ssl_tasks), arena_nodes=int(eng_cfg.get("arena_nodes", 0) or 0),
+                  # per-game evaluation cache (repeated positions are not evaluated twice; same games): on unless switched off
+                  eval_cache=bool(eng_cfg.get("eval_cache", True)))
     # engine.streams > 1: that many independent engines (own network instance and HIP stream each) share the games and
     # step concurrently -- same games, same records per game index, +3..4 % throughput at 2 (engine.SelfplayPool)
     streams = int(eng_cfg.get("streams", 1))
