@@ -225,7 +225,7 @@ static hipError_t launch_conv_z2_e(const GemmArgs& a, hipStream_t st) {
 
 hipError_t launch_conv_z2(const GemmArgs& a, hipStream_t st) {
     if (a.Cin % 64 != 0 || a.Npad % 320 != 0 || a.Mrows % 128 != 0) return hipErrorInvalidValue;
-    if (a.mul != nullptr || a.out_f32 != 0 || a.res != nullptr || a.tx_table != nullptr) return hipErrorInvalidValue;
+    if (a.mul != nullptr || a.out_f32 != 0 || a.res != nullptr) return hipErrorInvalidValue;
     if ((size_t)a.Mrows * a.ldo * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     if (a.gn_gamma != nullptr) {
         if (a.epi_act == ACT_SILU) return launch_conv_z2_e<1, ACT_SILU>(a, st);
