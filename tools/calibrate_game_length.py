@@ -16,7 +16,7 @@ leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1000.0
 be = M0Backend.from_state_dict(bench.R24_320, random_state_dict(bench.R24_320, seed=0, varied=True))
 cfg = eng.selfplay_cfg_from_dict(bench.SELFPLAY_CFG, concurrent_games=games, total_games=games, leaves_per_step=leaves,
-                                 virtual_loss_active=True, record_games=True)
+                                 virtual_loss_active=True, record_games=True, eval_cache=True)
 e = eng.SelfplayEngine(be, cfg)
 t0 = time.time(); recs = []; last = t0
 while e.running() and time.time() - t0 < budget:
@@ -36,7 +36,7 @@ out = {"games": len(recs), "games_requested": games, "complete": len(recs) == ga
        "max": float(moves.max()) if len(recs) else None,
        "draws": int(sum(r["draw"] for r in recs)), "resigned": int(sum(r["resigned"] for r in recs)),
        "decisive": int(sum(1 for r in recs if abs(r["result"]) == 1.0)),
-       "evals": int(st["evals"]), "sims": int(st["sims"]), "plies": int(st["plies"]), "seconds": dt,
+       "evals": int(st["evals"]), "evals_cached": int(st["evals_cached"]), "sims": int(st["sims"]), "plies": int(st["plies"]), "seconds": dt,
        "evals_per_ply": float(st["evals"] / max(1, st["plies"])),
        # the generation lasts as long as its longest game: passes of the hot path per searched ply once the searches have
        # drifted apart (in step it is ceil(sims / leaves) = 9 at 800 / 96)
