@@ -22,6 +22,11 @@ MEASURED plies/sec (searched and played plies counted by the engine) divided by 
 profiles/game_length.json (measured by running whole generations of games to completion with this engine/config;
 the basis is named in the JSON line).
 
+`engine.eval_cache` is on (as in the drop-in worker): a leaf reached more than once in a pass shares one batch row and a per-game
+cache serves positions evaluated in earlier passes, so ~5 % of the leaf evaluations cost no forward; every simulation is still
+played and the games are bit-identical with it off (`--no-eval-cache`; tests/test_eval_cache_gpu.py).  `evals_per_s` counts
+network evaluations only, `sims_per_s` all simulations.
+
 Extra objects in the JSON line:
   roofline      dominant kernel = 3x3 320->320 implicit-GEMM conv (MFMA-bound); achieved = algorithmic FLOP /
                 launch time from HIP events around every launch on the launch stream, summed over the timed region
@@ -322,7 +327,8 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.games} concurrent games per GPU x {args.gpus} GPU, {args.sims} sims/move, "
                                    f"R24-320 (57.56M params, {flops_eval / 1e9:.4f} GFLOP/eval) fp16 MFMA, {args.leaves} leaves/tree/step"
-                                   + (", 5 SSL heads in forward" if args.ssl else ""),
+                                   + (", 5 SSL heads in forward" if args.ssl else "")
+                                   + (", repeated leaf positions served by engine.eval_cache" if not args.no_eval_cache else ", engine.eval_cache off"),
                        "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
