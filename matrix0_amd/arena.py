@@ -122,6 +122,14 @@ def play_match(backend_a, backend_b, games: int, cfg: dict, seed: Optional[int] 
     ev = dict(cfg.get("eval", {}) or {})
     max_moves = int(max_moves_override) if max_moves_override is not None else int(ev.get("max_moves", 300))
     conc = int(concurrent_games or min(games, 256))
+    ecfg = dict(cfg.get("engine", {}) or {})
+    if bool((ecfg.get("compat", {}) or {}).get("tt_merge", False)) and not int(ecfg.get("arena_nodes", 0) or 0):
+        # per-side tables for the whole game: nothing is compacted, so a side's arena half must hold every node it creates in the
+        # game (~40 per simulation and search).  Size it, and keep the resident games within ~96 GB of node storage.
+        nodes = int(min(8_000_000, max(65536, num_sims * 40 * (max_moves // 2 + 2))))
+        per_game = 2 * nodes * 46 + 2 * 2 * nodes * 12                 # two halves of SoA nodes + two tables (keys + node ids, 2x)
+        conc = max(1, min(conc, int(96e9 // per_game)))
+        cfg = dict(cfg, engine=dict(ecfg, arena_nodes=nodes))
     c = arena_cfg_from_dict(cfg, games=games, num_sims=num_sims, max_moves=max_moves, temp=temp, temp_plies=temp_plies,
                             concurrent_games=min(conc, games), leaves_per_step=leaves_per_step, seed=seed)
     e = eng.ArenaEngine(backend_a, backend_b, c)
