@@ -105,3 +105,22 @@ def test_match_is_deterministic_for_a_seed_and_pgn_out(tmp_path):
     txt = (tmp_path / "pgn" / "game_0001.pgn").read_text()
     assert '[White "B"]' in txt and '[Black "A"]' in txt and "1. " in txt
     a.close(); b.close()
+
+
+def test_match_with_per_side_tables_plays_legal_games():
+    """`engine.compat.tt_merge` in play_match: one position table per side for the whole game (arena.py:157-158), node arenas sized by
+    play_match itself.  (Move-for-move parity of this mode with the untouched reference: tests/test_golden_selfplay_gpu.py.)"""
+    from matrix0_amd import arena
+    a, b = _backends()
+    cfg = dict(CFG, engine={"compat": {"tt_merge": True}})
+    score = arena.play_match(a, b, 4, cfg, seed=21, num_sims=24, temp=1.0, temp_plies=4, max_moves_override=16, concurrent_games=4,
+                             leaves_per_step=8)
+    st = arena.last_match_stats
+    assert len(st["records"]) == 4 and st["a_wins"] + st["b_wins"] + st["draws"] == 4 and score == st["score"]
+    for r in st["records"]:
+        board, moves = _replay(r, 16)
+        assert 1 <= len(r["played"]) <= 16
+    # more evaluations than the fresh-tree match of the same games: roots found in a side's table are evaluated again
+    arena.play_match(a, b, 4, CFG, seed=21, num_sims=24, temp=1.0, temp_plies=4, max_moves_override=16, concurrent_games=4, leaves_per_step=8)
+    assert st["evals"] != arena.last_match_stats["evals"]
+    a.close(); b.close()
