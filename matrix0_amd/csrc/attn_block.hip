@@ -61,6 +61,12 @@ __device__ __forceinline__ float ab_row_sum(float v) {
 #define AB_DBG 0
 #endif
 #define AB_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef AB_STAMP
+__device__ unsigned long long* g_ab_stamp;        // [blocks][16] s_memtime stamps of wave 0 (tools/ubench/attn_block_bench.hip)
+#define AB_ST(k) do { if (tid == 0) g_ab_stamp[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_ST(k) do {} while (0)
+#endif
 #define AB_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int ACT>
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     const size_t b0 = (size_t)blockIdx.x * 2;
     const char* xg = reinterpret_cast<const char*>(a.x) + b0 * 64 * 640;
 
+    AB_ST(0);
     // ---- prologue: the two boards' rows and the first three weight pieces
 #pragma unroll
     for (int n = 0; n < 10; ++n) {
@@ -149,6 +156,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
 #pragma unroll 1
     for (int g = 0; g < (AB_DBG == 1 ? 0 : AB_GROUPS); ++g) {
         const int t0 = g * AB_PIECES_PER_GROUP;
+        if (g == 5) AB_ST(8);
+        if (g == 6) AB_ST(11);
         float4v qa[2][3];
         static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
             static_for<0, 3>([&](auto j_) __attribute__((always_inline)) { qa[decltype(i_)::value][decltype(j_)::value] = zero4; });
@@ -197,6 +206,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                 });
             });
         });
+        if (g == 0) AB_ST(1);
+        if (g == 5) AB_ST(5);
         // ---- stage q, k (token-major) and v (transposed) as fp16
         static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
             static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         AB_LGKM0();                                           // raw barrier: __syncthreads() would drain the weight DMA
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (g == 5) AB_ST(6);
         // ---- 2. attention of this wave's (board, head, query half)
         if (AB_DBG != 2) {
             const char* Kb = smem + AB_QK + 8192 + ahl * 4096 + aboard * 64 * 32;
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             // (inline asm: before an ordinary LDS store hipcc waits for every LDS-DMA in flight, vmcnt(0))
             asm volatile("ds_write_b128 %0, %1" :: "v"((uint32_t)(uintptr_t)Qp), "v"(ov) : "memory");
         }
+        if (g == 5) AB_ST(7);
         // ---- 3. proj accumulate: two pieces of 160 output channels
         half8 of;
         static_for<0, 2>([&](auto hh_) __attribute__((always_inline)) {
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             });
         });
     }
+    AB_ST(2);
     // every wave's DMA (the three pad pieces included) has landed and every wave has left the ring before it is reused
     AB_WAIT(0);
     __syncthreads();
@@ -367,7 +381,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             *reinterpret_cast<uint4*>(og + rl * 640 + src * 16) = v;
         }
     };
+    AB_ST(3);
     flush(a.y);
+    AB_ST(4);
     if (a.y2 == nullptr) return;
     // ---- second output: act(GroupNorm16(y)) for the next residual block (statistics per board and 16-channel group)
     __syncthreads();
@@ -412,7 +428,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         });
         *reinterpret_cast<half4v*>(xrow + pos * 16) = h;
     });
+    AB_ST(9);
     flush(a.y2);
+    AB_ST(10);
 }
 
 hipError_t launch_attn_block(const AttnBlockArgs& a, hipStream_t st) {

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 static void pack(const std::vector<float>& wq, const std::vector<float>& wp, const std::vector<float>& rb,
                  std::vector<_Float16>& buf, std::vector<_Float16>& bb) {
@@ -85,6 +86,10 @@ int main(int argc, char** argv) {
     a.x = dx; a.wpack = dw; a.bias = dbb; a.mask = dm; a.ln_g = dlg; a.ln_b = dlb; a.gn2_gamma = dg2; a.gn2_beta = db2;
     a.y = dy; a.y2 = dy2; a.B = boards; a.ln_count = C; a.act = ACT_SILU; a.mix = 0.3f; a.inv_sqrt_d = 0.25f;
     hipStream_t st; hipStreamCreate(&st);
+#ifdef AB_STAMP
+    unsigned long long* dst_ab; hipMalloc(&dst_ab, (size_t)(boards / 2) * 16 * 8); hipMemset(dst_ab, 0, (size_t)(boards / 2) * 16 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ab_stamp), &dst_ab, sizeof(dst_ab));
+#endif
     hipError_t e = launch_attn_block(a, st);
     hipError_t e2 = hipStreamSynchronize(st);
     if (e != hipSuccess || e2 != hipSuccess) { printf("launch failed: %s / %s\n", hipGetErrorString(e), hipGetErrorString(e2)); return 1; }
@@ -182,6 +187,22 @@ int main(int argc, char** argv) {
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1000.0 / iters;
     const double flop = 2.0 * (double)M * C * (4.0 * C) + 4.0 * (double)boards * H * 64 * 64 * 16;
+#ifdef AB_STAMP
+    {
+        const int nb2 = boards / 2;
+        std::vector<unsigned long long> hs((size_t)nb2 * 16);
+        hipMemcpy(hs.data(), dst_ab, hs.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[] = {"prologue -> first group's qkv done", "group 5: qkv GEMM", "staging", "attention", "proj (to next group start)",
+                               "main loop total", "drain + residual + LayerNorm", "flush y", "GroupNorm + y2 math", "flush y2"};
+        const int a_[] = {0, 8, 5, 6, 7, 0, 2, 3, 4, 9}, b_[] = {1, 5, 6, 7, 11, 2, 3, 4, 9, 10};
+        for (int k = 0; k < 10; ++k) {
+            std::vector<double> d;
+            for (int b = 0; b < nb2; ++b) d.push_back((double)(hs[(size_t)b * 16 + b_[k]] - hs[(size_t)b * 16 + a_[k]]));
+            std::sort(d.begin(), d.end());
+            printf("  %-40s median %8.0f cycles\n", names[k], d[d.size() / 2]);
+        }
+    }
+#endif
     printf("attn_block boards %d: %.1f us / launch, %.3f PFLOP/s, %.2f TB/s (x + y + y2)\n", boards, us, flop / us * 1e-9,
            3.0 * M * C * 2 / us * 1e-6);
     return nbad ? 2 : 0;
