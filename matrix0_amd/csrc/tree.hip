@@ -892,17 +892,25 @@ __global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_
         const uint64_t* TK = d.tt_keys + ((size_t)g * 2 + s) * d.tt_cap;
         const int* TN = d.tt_nodes + ((size_t)g * 2 + s) * d.tt_cap;
         int node = slot == -3 ? -1 : tt_lookup(TK, TN, d.tt_cap, tt_key_of(gd->root_pos), lane);
+        // a half that cannot take another search's worth of nodes starts over: its table is dropped and the search begins from a
+        // fresh root (what the reference's _cleanup_memory does to an over-full table); engine.arena_nodes sizes it for a game
+        if (nxt + 4 * M0_MAX_CHILDREN >= d.t.cap) {
+            uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + ((size_t)g * 2 + s) * d.tt_cap);
+            for (int i = lane; i < d.tt_cap / 2; i += 64) tk[i] = make_uint4(0, 0, 0, 0);
+            nxt = 0; node = -1;
+            __syncthreads();
+        }
         const bool found = node >= 0;
         if (lane == 0) {
             if (slot != -3) gd->side_next[prev_side] = prev_next;
             else { gd->side_next[0] = 0; gd->side_next[1] = 0; }
             if (!found) {
-                node = nxt < d.t.cap ? nxt : d.t.cap - 1;
+                node = nxt;
                 A.prior[node] = 0.0; A.w[node] = 0.0; A.q[node] = 0.0; A.n[node] = 0; A.vl[node] = 0; A.cbase[node] = -1; A.nch[node] = -1;
                 A.mv[node] = 0; A.midx[node] = 0;
                 nxt = node + 1;
             }
-            gd->arena = s; gd->root = node; gd->next = nxt; gd->overflow = nxt >= d.t.cap ? 1 : 0;
+            gd->arena = s; gd->root = node; gd->next = nxt; gd->overflow = 0;
             gd->root_fresh = found ? 0 : 1; gd->root_found = found ? 1 : 0;
         }
         return;

@@ -124,3 +124,19 @@ def test_match_with_per_side_tables_plays_legal_games():
     arena.play_match(a, b, 4, CFG, seed=21, num_sims=24, temp=1.0, temp_plies=4, max_moves_override=16, concurrent_games=4, leaves_per_step=8)
     assert st["evals"] != arena.last_match_stats["evals"]
     a.close(); b.close()
+
+
+def test_per_side_tables_start_over_when_their_arena_is_full():
+    """A side's arena half that cannot take another search's nodes drops its table and starts from a fresh root (the reference
+    prunes an over-full table too): with the smallest arena the games still run to their end and stay legal."""
+    from matrix0_amd import arena
+    a, b = _backends()
+    cfg = dict(CFG, engine={"compat": {"tt_merge": True}, "arena_nodes": 4096})
+    arena.play_match(a, b, 2, cfg, seed=33, num_sims=32, temp=1.0, temp_plies=6, max_moves_override=30, concurrent_games=2,
+                     leaves_per_step=8)
+    st = arena.last_match_stats
+    assert len(st["records"]) == 2
+    for r in st["records"]:
+        _replay(r, 30)
+        assert len(r["played"]) >= 20                    # no search ended without visits (that would end the game early)
+    a.close(); b.close()
