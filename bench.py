@@ -22,10 +22,11 @@ MEASURED plies/sec (searched and played plies counted by the engine) divided by 
 profiles/game_length.json (measured by running whole generations of games to completion with this engine/config;
 the basis is named in the JSON line).
 
-`engine.eval_cache` is on (as in the drop-in worker): a leaf reached more than once in a pass shares one batch row and a per-game
-cache serves positions evaluated in earlier passes, so ~5 % of the leaf evaluations cost no forward; every simulation is still
-played and the games are bit-identical with it off (`--no-eval-cache`; tests/test_eval_cache_gpu.py).  `evals_per_s` counts
-network evaluations only, `sims_per_s` all simulations.
+`value` is measured with every leaf going through the network (`engine.eval_cache` off).  The drop-in worker's default has the
+cache on -- a leaf reached more than once in a pass shares one batch row and a per-game cache serves positions evaluated in
+earlier passes, ~5 % of the leaf evaluations; every simulation is still played and the games are bit-identical
+(tests/test_eval_cache_gpu.py) -- so the same K plies are timed a second time with it on and reported in `eval_cache`
+(`value_with_eval_cache`); `--no-eval-cache` skips that region, `--eval-cache-in-value` measures `value` itself with it on.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = 3x3 320->320 implicit-GEMM conv (MFMA-bound); achieved = algorithmic FLOP /
@@ -191,7 +192,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=4, help="torch threads per CPU-baseline worker process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval-cache", action="store_true",
-                    help="switch the per-game evaluation cache off (every leaf goes through the network, repeated positions too)")
+                    help="skip the second timed region (the same plies with engine.eval_cache on, reported in `eval_cache`)")
+    ap.add_argument("--eval-cache-in-value", action="store_true",
+                    help="measure `value` itself with engine.eval_cache on (the drop-in worker's default) instead of off")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
                          "+3..4 %% games/s, but per-launch kernel timings then include the other stream's kernels, so the "
@@ -239,20 +242,6 @@ def main():
     # unbounded mode (total_games=0): finished games are replaced forever, so every rank (and every pool stream) draws its
     # game indices from its own block of 2^24 -- no (seed, index) pair is ever played twice in one run
     first_index = rank * (1 << 24)
-    cfg = eng.selfplay_cfg_from_dict(cfg_dict, concurrent_games=args.games, total_games=0,
-                                     first_game_index=first_index, leaves_per_step=args.leaves,
-                                     virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False,
-                                     eval_cache=not args.no_eval_cache)
-    if args.streams > 1:
-        made = [be]
-        e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
-                             cfg_dict, streams=args.streams, concurrent_games=args.games, total_games=0,
-                             first_game_index=first_index, leaves_per_step=args.leaves,
-                             virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False,
-                             eval_cache=not args.no_eval_cache)
-    else:
-        e = eng.SelfplayEngine(be, cfg)
-
     def sync():
         torch.cuda.synchronize()
         if distributed:
@@ -261,38 +250,68 @@ def main():
 
     substeps = -(-args.sims // args.leaves)          # passes of the hot path per searched ply (all games in step)
 
-    def run_plies(n):
-        """Passes of the hot path until `n` more plies per resident game have been searched and played (counted by the
-        engine).  The games search in step, so the region starts and ends right after a round of moves: the measured
-        plies / time does not depend on where a fixed number of passes would have cut the searches."""
-        target = e.stats()["plies"] + n * args.games
-        passes = 0
-        while e.stats()["plies"] < target and passes < 4 * n * substeps:
-            e.step(1)
-            passes += 1
-        return passes
+    def measure(eval_cache: bool):
+        """One engine, warm-up, then the timed region of exactly `--steps` searched plies per resident game."""
+        kw = dict(concurrent_games=args.games, total_games=0, first_game_index=first_index, leaves_per_step=args.leaves,
+                  virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache)
+        if args.streams > 1:
+            made = [be]
+            e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
+                                 cfg_dict, streams=args.streams, **kw)
+        else:
+            e = eng.SelfplayEngine(be, eng.selfplay_cfg_from_dict(cfg_dict, **kw))
 
-    if args.warmup > 0:
-        run_plies(args.warmup)
-    be.profile_enable(True)
-    be.profile_get(reset=True)
-    s0 = e.stats()
-    sync()
-    t0 = time.perf_counter()
-    passes_timed = run_plies(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    s1 = e.stats()
-    conv_ms, conv_flop, conv_launches = be.profile_get(reset=True)
-    be.profile_enable(False)
+        def run_plies(n):
+            """Passes of the hot path until `n` more plies per resident game have been searched and played (counted by the
+            engine).  The games search in step, so the region starts and ends right after a round of moves: the measured
+            plies / time does not depend on where a fixed number of passes would have cut the searches."""
+            target = e.stats()["plies"] + n * args.games
+            passes = 0
+            while e.stats()["plies"] < target and passes < 4 * n * substeps:
+                e.step(1)
+                passes += 1
+            return passes
 
-    d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host", "ms_total",
-                                    "evals_cached")}
-    counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
-                         d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed, d["evals_cached"]], dtype=np.float64)
-    dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
-    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all, cached = [float(x) for x in tot]
+        if args.warmup > 0:
+            run_plies(args.warmup)
+        be.profile_enable(True)
+        be.profile_get(reset=True)
+        s0 = e.stats()
+        sync()
+        t0 = time.perf_counter()
+        passes_timed = run_plies(args.steps)
+        sync()
+        dt = time.perf_counter() - t0
+        s1 = e.stats()
+        conv_ms, conv_flop, conv_launches = be.profile_get(reset=True)
+        tail = getattr(be, "last_tail_profile", (0.0, 0))
+        be.profile_enable(False)
+        if args.streams > 1:
+            for x in e.engines:
+                x.close()                                   # the first backend is `be`: it stays open for the next measurement
+            for b_ in e.backends[1:]:
+                b_.close()
+            e.engines, e.backends = [], []
+        else:
+            e.close()
+        d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host",
+                                        "ms_total", "evals_cached")}
+        counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
+                             d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed, d["evals_cached"]], dtype=np.float64)
+        dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
+        return dt_max, [float(x) for x in tot], tail
+
+    # `value` is measured with EVERY leaf going through the network (evaluation cache off: round 2's definition of the metric).
+    # The product default (drop-in worker) has engine.eval_cache on; the same K plies are then timed a second time with it on
+    # and reported beside `value` in `eval_cache` (--no-eval-cache: skip that; --eval-cache-in-value: `value` itself with it on)
+    primary_cache = bool(args.eval_cache_in_value)
+    dt_max, tot, tail_prof = measure(primary_cache)
+    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all, cached = tot
     passes = max(1.0, passes_all / args.gpus)           # passes per rank in the timed region
+    second = None
+    if not args.no_eval_cache and not primary_cache:
+        dt2, tot2, _ = measure(True)
+        second = {"dt": dt2, "evals": tot2[0], "plies": tot2[1], "gfin": tot2[2], "sims": tot2[9], "passes": tot2[10], "cached": tot2[11]}
 
     if rank == 0:
         ppg, basis_src = game_length_basis()
@@ -305,7 +324,7 @@ def main():
                      f"{int(gfin)} games finished")
         achieved = (conv_flop / (conv_ms * 1e-3)) if conv_ms > 0 else 0.0
         # launch mix: conv2 of every block (and the interaction conv) also carries the fused block tail
-        tail_ms, tail_n = getattr(be, "last_tail_profile", (0.0, 0))
+        tail_ms, tail_n = tail_prof
         plain_n = conv_launches - tail_n
         flop_per_launch = conv_flop / conv_launches if conv_launches else 0.0
         mix = {"with_fused_tail": {"launches": int(tail_n), "avg_launch_us": (tail_ms * 1e3 / tail_n) if tail_n else None,
@@ -328,16 +347,26 @@ def main():
             "config": {"workload": f"{args.games} concurrent games per GPU x {args.gpus} GPU, {args.sims} sims/move, "
                                    f"R24-320 (57.56M params, {flops_eval / 1e9:.4f} GFLOP/eval) fp16 MFMA, {args.leaves} leaves/tree/step"
                                    + (", 5 SSL heads in forward" if args.ssl else "")
-                                   + (", repeated leaf positions served by engine.eval_cache" if not args.no_eval_cache else ", engine.eval_cache off"),
+                                   + (", repeated leaf positions served by engine.eval_cache" if primary_cache
+                                      else ", every leaf evaluated by the network (engine.eval_cache off)"),
                        "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
-            # every simulation is played; a leaf whose position this game evaluated before (a transposition inside the search, a
-            # position of a discarded subtree) is expanded from the stored value + legal logits instead of a second forward --
-            # the reference's position table does not evaluate a transposed node twice either (mcts.py:919).  Games are
-            # bit-identical with the cache off (tests/test_eval_cache_gpu.py); `evals_per_s` counts network evaluations only.
-            "eval_cache": {"enabled": not args.no_eval_cache, "evaluations_from_cache": int(cached),
-                           "share_of_leaf_evaluations": cached / max(1.0, cached + evals)},
+            # second timed region of the same K plies with the product default engine.eval_cache on (module docstring)
+            "eval_cache": (None if second is None and not primary_cache else (
+                {"in_value": True, "evaluations_from_cache": int(cached), "share_of_leaf_evaluations": cached / max(1.0, cached + evals)}
+                if primary_cache else
+                {"in_value": False,
+                 "value_with_eval_cache": (second["gfin"] / second["dt"]) if second["gfin"] >= MIN_FINISHED * args.gpus
+                 else (second["plies"] / second["dt"]) / ppg,
+                 "plies_per_s": second["plies"] / second["dt"], "sims_per_s": second["sims"] / second["dt"],
+                 "evals_per_s": second["evals"] / second["dt"], "evaluations_from_cache": int(second["cached"]),
+                 "share_of_leaf_evaluations": second["cached"] / max(1.0, second["cached"] + second["evals"]),
+                 "ms_per_step": second["dt"] * 1e3 / max(1, args.steps),
+                 "note": "same engine configuration and the same K plies timed a second time with engine.eval_cache on (the "
+                         "drop-in worker's default): a leaf reached twice in a pass shares one batch row, positions evaluated "
+                         "in earlier passes come from a per-game cache; every simulation is played and the games are "
+                         "bit-identical (tests/test_eval_cache_gpu.py)"})),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "passes_per_step": passes / max(1, args.steps), "ms_per_pass": dt_max * 1e3 / passes,
             # the timed region is the friendliest regime: all resident searches are in step, so every pass is a full batch and a
@@ -345,7 +374,8 @@ def main():
             # plies; playout caps differ): `whole_generation` is what tools/calibrate_game_length.py measured end to end
             "passes_per_ply": {"in_step_timed_region": passes / max(1, args.steps),
                                "whole_generation": generation_passes_per_ply()[0],
-                               "whole_generation_games_per_s_end_to_end": generation_passes_per_ply()[1]},
+                               "whole_generation_games_per_s_end_to_end": generation_passes_per_ply()[1],
+                               "whole_generation_note": "profiles/game_length.json: 256 games played to completion with engine.eval_cache on"},
             "time_split_ms_per_pass": {"net": ms_net / args.gpus / passes, "tree": ms_tree / args.gpus / passes,
                                        "host": ms_host / args.gpus / passes},
             "roofline": {"bound": "mfma", "kernel": "conv_zs_kernel<*> (3x3 320->320 implicit GEMM, zero padding skipped, MFMA 16x16x32 f16)",
@@ -359,7 +389,7 @@ def main():
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    e.close()
+    be.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,11 +17,9 @@ python bench.py --ssl --no-cpu-baseline > $OUT/$TAG.bench_ssl.json 2> $OUT/$TAG.
 echo "[profile] bench --ssl done (BASELINE configs[3])"
 python bench.py --sims 1600 --steps 10 --no-cpu-baseline > $OUT/$TAG.bench_sims1600.json 2> $OUT/$TAG.bench_sims1600.err || exit 1
 echo "[profile] bench --sims 1600 done (BASELINE configs[4] search shape on one GPU)"
-python bench.py --no-eval-cache --no-cpu-baseline > $OUT/$TAG.bench_no_eval_cache.json 2> $OUT/$TAG.bench_no_eval_cache.err || exit 1
-echo "[profile] bench --no-eval-cache done"
 python bench.py --streams 2 --no-cpu-baseline > $OUT/$TAG.bench_streams2.json 2> $OUT/$TAG.bench_streams2.err || exit 1
 echo "[profile] bench --streams 2 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/$TAG.bench_prof.json 2> $OUT/$TAG.stats.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval-cache > $OUT/$TAG.bench_prof.json 2> $OUT/$TAG.stats.err || exit 1
 echo "[profile] kernel stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.netstats -- python3 tools/bench_net.py $B > $OUT/$TAG.netstats.log 2>&1 || exit 1
 echo "[profile] forward stats done"

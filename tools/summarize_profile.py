@@ -29,7 +29,7 @@ def copy(src_pat, dst):
     return f
 
 
-for name in ("bench", "bench_ssl", "bench_sims1600", "bench_no_eval_cache", "bench_streams2"):
+for name in ("bench", "bench_ssl", "bench_sims1600", "bench_streams2"):
     f = os.path.join(G, f"{tag}.{name}.json")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, f"{tag}_{name}.json"))
