@@ -19,8 +19,10 @@
 // All GEMM tiles are MFMA 16x16x32 in the "swapped" orientation (A = weights, B = activations): the accumulator then
 // holds 4 consecutive channels of one token per lane = one 8-byte LDS write.
 // The weights of the whole block are one stream of 70 pieces of 12 KB (host-packed in LDS image order, net.hip)
-// through a 4-slot ring filled three pieces ahead by global_load_lds (two DMA instructions per wave and piece, so every
-// wave's vmcnt bookkeeping is identical); one barrier per piece.
+// through a 4-slot ring filled by global_load_lds (two DMA instructions per wave and piece, so every wave's vmcnt
+// bookkeeping is identical); one barrier per piece.  The proj pieces of a group are consumed together with the qkv pieces
+// of the next one as one software-pipelined sequence: the fragments of the next half-piece are read from LDS (untracked
+// inline-asm reads, counted lgkmcnt waits) while the MFMAs of the current one issue.
 #include "kernel_common.h"
 #include "conv_epilogue.h"
 
@@ -43,6 +45,24 @@ constexpr int AB_LDS = AB_PAR + 4 * 320 * 4;              // 161280
 __device__ __forceinline__ void ab_dma16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// 64 bytes per lane from global memory that the compiler does not track (the caller waits: vmcnt)
+__device__ __forceinline__ void ab_load64(half8& b0, half8& b1, half8& b2, half8& b3, const half8* p) {
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(p) : "memory");
+}
+// one 16-byte LDS read the compiler does not track (the caller waits: lgkmcnt)
+template <int OFF>
+__device__ __forceinline__ void ab_lds16(half8& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// ... and the wait: at most N younger LDS reads outstanding; the operands tie their first use to this point
+template <int N>
+__device__ __forceinline__ void ab_lds_arrived(half8& f0, half8& f1, half8& f2, half8& f3, half8& f4, half8& f5) {
+    static_assert(N == 0 || N == 5, "");
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) :: "memory");
 }
 template <int CTRL>
 __device__ __forceinline__ float ab_dpp(float v) {
@@ -91,7 +111,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     }
     // a piece is 12 x 1 KB: every wave issues one full 16-byte DMA and one with its upper 32 lanes masked off (1.5 KB per
     // wave), so the count of outstanding vector-memory operations is the same in all 8 waves.  (global_load_lds_dwordx3
-    // would give 16 x 768 B, but on gfx950 it places lane i's 12 bytes at base + 16 i.)
+    // would give 16 x 768 B, but on gfx950 it places lane i's 12 bytes at base + 16 i.  Twelve full instructions -- waves 0-3
+    // two, waves 4-7 one, with per-wave wait counts -- measured the same or slower.)
     const char* wsrc = reinterpret_cast<const char*>(a.wpack) + w * 1536 + lane * 16;
     char* const ring_w = smem + AB_RING + w * 1536;
     auto issue = [&](int t) __attribute__((always_inline)) {
@@ -100,6 +121,11 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         ab_dma16(s, d);
         if (lane < 32) ab_dma16(s + 1024, d + 1024);
     };
+    // AB_WAIT(4) = all but this wave's two youngest pieces have landed.  Only LDS-DMA operations may be outstanding at a
+    // counted wait: loads into registers and loads into LDS do not retire in one order (measured: a later DMA retired
+    // before an earlier register load and vmcnt(1) let a wave read its bias registers early), so a count over both kinds
+    // proves nothing about either.  The bias loads below are therefore issued after a sequence's last counted wait and
+    // waited for with vmcnt(0).
     issue(0); issue(1); issue(2);
     if (tid < 320) {
         float* par = reinterpret_cast<float*>(smem + AB_PAR);
@@ -119,14 +145,15 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     const int au = w >> 1, aboard = au >> 1, ahl = au & 1, aqt = w & 1;
     const int aq = aqt * 32 + r31;
     // visibility of key (kt, r) from query aq as a multiplicand, accumulator order: key = kt*32 + 8(r>>2) + 4 half + (r&3)
-    float visf[32];
+    // (fp16 pairs: 16 registers; the products below take them as the fp16 operand of a mixed-precision FMA)
+    half2v visp[16];
     {
         const uint64_t m = a.mask[aq];
         static_for<0, 32>([&](auto i_) __attribute__((always_inline)) {
             constexpr int i = decltype(i_)::value;
             constexpr int kt = i >> 4, r = i & 15;
             const int key = kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            visf[i] = (float)((m >> key) & 1);
+            visp[i >> 1][i & 1] = (_Float16)(float)((m >> key) & 1);
         });
     }
     float wm_, wu_;   // output weights of the masked / unmasked branch (resnet.py:154-174)
@@ -140,73 +167,120 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     const int xrow0 = 32 * wm + l15;
     const int xsw = (xrow0 >> 1) & 7;
     const int xe0 = ((lq ^ xsw) & 7) * 16, xe1 = (((4 + lq) ^ xsw) & 7) * 16;
-    const char* xb0 = smem + AB_X + xrow0 * 640;
-    const char* xb1 = xb0 + 16 * 640;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t xa[2] = {lds0 + AB_X + xrow0 * 640 + xe0, lds0 + AB_X + xrow0 * 640 + xe1};      // rows xrow0 and (+16 * 640) xrow0 + 16
     const int wsw = (l15 >> 1) & 7;
     const int wq0 = (3 * wn * 16 + l15) * 128 + ((lq ^ wsw) & 7) * 16;            // qkv piece, kk = 0
     const int wq1 = (3 * wn * 16 + l15) * 128 + (((4 + lq) ^ wsw) & 7) * 16;      // kk = 1
-    const int wpo = l15 * 64 + ((lq ^ (l15 >> 2)) & 3) * 16;                      // proj piece
-    const char* ring = smem + AB_RING;
+    // proj piece: 64-byte rows; a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (one row
+    // quad of lq = 0 / 2 next to two of lq = 1 / 3): chunk ^ (4 - quad) & 3 gives the 16 lanes of a group 16 different bank quads
+    const int wpo = l15 * 64 + ((lq ^ (4 - (l15 >> 2))) & 3) * 16;
+    const uint32_t ring_a = lds0 + AB_RING;
+    const uint32_t of_a = lds0 + AB_QK + (lq >> 1) * 4096 + (16 * w + l15) * 32 + (lq & 1) * 16;   // this wave's O rows (proj operand)
 
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4v oc[20];
     static_for<0, 20>([&](auto j_) __attribute__((always_inline)) { oc[decltype(j_)::value] = zero4; });
 
-#pragma unroll 1
-    for (int g = 0; g < (AB_DBG == 1 ? 0 : AB_GROUPS); ++g) {
-        const int t0 = g * AB_PIECES_PER_GROUP;
-        if (g == 5) AB_ST(8);
-        if (g == 6) AB_ST(11);
-        float4v qa[2][3];
+    // The block's 70 weight pieces are consumed as one sequence per head group: [proj piece 0, 1 of the PREVIOUS group,] qkv
+    // piece 0..4 of this group, each piece in two halves (one k-step of the qkv GEMM / 80 output channels of the proj).
+    // The fragments of half u+1 (weights from the ring, trunk rows / O from LDS) are read into the second register set before
+    // the MFMAs of half u are issued, so a half's LDS reads run under the matrix work of the half before it instead of in
+    // front of their own (both waves of a SIMD sit at the same barrier: nothing else would overlap them).  Per piece
+    // boundary: this wave's reads of piece i are complete (lgkmcnt) and its parts of piece i+1 have landed (vmcnt) ->
+    // barrier -> read the first half of piece i+1 -> DMA piece i+4 into the slot of piece i -> MFMAs of the last half of i.
+    half8 fs[2][5];
+    half8 of;
+    float4v qa[2][3];
+    half8 bias8[4];
+    auto sequence = [&](auto hp_, auto hq_, const int T, const int g) __attribute__((always_inline)) {
+        constexpr bool HP = decltype(hp_)::value, HQ = decltype(hq_)::value;
+        constexpr int NP = (HP ? 2 : 0) + (HQ ? 5 : 0), NU = 2 * NP;
+        constexpr int BU = NU - 3;                            // the half under which the bias is requested: after the last counted wait
+        // (fragment reads are inline asm with counted lgkmcnt waits below: after any inline asm hipcc's own waits are
+        // lgkmcnt(0), which would put every half's reads in front of the MFMAs of the half before it again)
+        auto load = [&](auto u_) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_)::value, S = u & 1, i = u >> 1, kk = u & 1;
+            const uint32_t slot = ring_a + (uint32_t)(((T + i) & 3) * AB_PIECE);
+            if constexpr (HP && i < 2) {
+                if constexpr (u == 0) ab_lds16<0>(of, of_a);
+                const uint32_t pa = slot + wpo;
+                static_for<0, 5>([&](auto jj_) __attribute__((always_inline)) {
+                    constexpr int jj = decltype(jj_)::value;
+                    ab_lds16<(5 * kk + jj) * 1024>(fs[S][jj], pa);
+                });
+            } else {
+                constexpr int p = i - (HP ? 2 : 0);
+                ab_lds16<128 * p>(fs[S][3], xa[kk]);
+                ab_lds16<128 * p + 16 * 640>(fs[S][4], xa[kk]);
+                const uint32_t wa = slot + (kk ? wq1 : wq0);
+                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_)::value;
+                    ab_lds16<j * 2048>(fs[S][j], wa);
+                });
+            }
+        };
+        // the set of half u is in registers once at most N younger LDS reads are outstanding
+        auto arrived = [&](auto u_, auto n_) __attribute__((always_inline)) {
+            constexpr int S = decltype(u_)::value & 1;
+            ab_lds_arrived<decltype(n_)::value>(fs[S][0], fs[S][1], fs[S][2], fs[S][3], fs[S][4], of);
+        };
+        auto mma = [&](auto u_) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_)::value, S = u & 1, i = u >> 1, kk = u & 1;
+            if constexpr (HP && i < 2) {
+                static_for<0, 5>([&](auto jj_) __attribute__((always_inline)) {
+                    constexpr int c = 10 * i + 5 * kk + decltype(jj_)::value;
+                    oc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[S][decltype(jj_)::value], of, oc[c], 0, 0, 0);
+                });
+            } else {
+                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_)::value;
+                    qa[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[S][j], fs[S][3], qa[0][j], 0, 0, 0);
+                    qa[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fs[S][j], fs[S][4], qa[1][j], 0, 0, 0);
+                });
+            }
+        };
+        AB_LGKM0();                                           // this wave's O rows of the previous group are in LDS
+        AB_WAIT(4);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load(std::integral_constant<int, 0>{});
+        issue(T + 3);
+        static_for<0, NU>([&](auto u_) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_)::value;
+            if constexpr (u + 1 < NU) {
+                if constexpr (u & 1) {
+                    arrived(u_, std::integral_constant<int, 0>{});
+                    AB_WAIT(4);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if constexpr (HP && HQ && (u == 1 || u == 3 || u == 7 || u == 11)) { if (g == 5) AB_ST(u == 1 ? 12 : u == 3 ? 13 : u == 7 ? 14 : 15); }
+                }
+                load(std::integral_constant<int, u + 1>{});
+                if constexpr (u & 1) issue(T + (u >> 1) + 4);
+                else arrived(u_, std::integral_constant<int, 5>{});
+            } else {
+                arrived(u_, std::integral_constant<int, 0>{});
+            }
+            if constexpr (HQ && u == BU) {
+                // relative-position bias of (head, query half) in accumulator order: 64 B per lane, requested after the
+                // sequence's last counted wait (see above) and waited for with vmcnt(0) before the scores
+                // (inline asm: at the first use of an ordinary load's result hipcc waits vmcnt(0) wherever that use lands)
+                const half8* bp = reinterpret_cast<const half8*>(a.bias) + ((size_t)((2 * g + ahl) * 2 + aqt) * 64 + lane) * 4;
+                ab_load64(bias8[0], bias8[1], bias8[2], bias8[3], bp);
+            }
+            mma(u_);
+            __builtin_amdgcn_sched_barrier(0);                // the next half's wait stays behind these MFMAs
+        });
+    };
+
+    auto zero_qa = [&]() __attribute__((always_inline)) {
         static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
             static_for<0, 3>([&](auto j_) __attribute__((always_inline)) { qa[decltype(i_)::value][decltype(j_)::value] = zero4; });
         });
-        half8 bias8[4];
-        // ---- 1. qkv GEMM of the group: 5 pieces of K = 64
-        static_for<0, 5>([&](auto p_) __attribute__((always_inline)) {
-            constexpr int p = decltype(p_)::value;
-            // the activation fragments do not depend on the weight DMA: read them ahead of the wait and the barrier
-            half8 xf[2][2];
-            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
-                constexpr int kk = decltype(kk_)::value;
-                constexpr int ks = 2 * p + kk;
-                const int xo = 128 * (ks >> 1) + ((ks & 1) ? xe1 : xe0);
-                xf[kk][0] = *reinterpret_cast<const half8*>(xb0 + xo);
-                xf[kk][1] = *reinterpret_cast<const half8*>(xb1 + xo);
-            });
-            if constexpr (p < 3) AB_WAIT(4); else AB_WAIT(8);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const char* slot = ring + ((t0 + p) & 3) * AB_PIECE;
-            half8 wf[2][3];
-            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
-                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
-                    constexpr int kk = decltype(kk_)::value, j = decltype(j_)::value;
-                    wf[kk][j] = *reinterpret_cast<const half8*>(slot + (kk ? wq1 : wq0) + j * 2048);
-                });
-            });
-            asm volatile("" ::: "memory");
-            issue(t0 + p + 3);
-            if constexpr (p == 2) {
-                // relative-position bias of (head, query half) in accumulator order: 64 B per lane
-                const half8* bp = reinterpret_cast<const half8*>(a.bias) +
-                                  ((size_t)((2 * g + ahl) * 2 + aqt) * 64 + lane) * 4;
-                // (inline asm: at the first use of an ordinary load's result hipcc waits vmcnt(0), which would drain the
-                // weight pieces in flight; the counted wait before the scores below covers these four)
-                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                             "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
-                             : "=&v"(bias8[0]), "=&v"(bias8[1]), "=&v"(bias8[2]), "=&v"(bias8[3]) : "v"(bp) : "memory");
-            }
-            static_for<0, 2>([&](auto kk_) __attribute__((always_inline)) {
-                static_for<0, 3>([&](auto j_) __attribute__((always_inline)) {
-                    constexpr int kk = decltype(kk_)::value, j = decltype(j_)::value;
-                    qa[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], xf[kk][0], qa[0][j], 0, 0, 0);
-                    qa[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], xf[kk][1], qa[1][j], 0, 0, 0);
-                });
-            });
-        });
-        if (g == 0) AB_ST(1);
+    };
+    auto stage_and_attend = [&](const int g) __attribute__((always_inline)) {
         if (g == 5) AB_ST(5);
         // ---- stage q, k (token-major) and v (transposed) as fp16
         static_for<0, 2>([&](auto i_) __attribute__((always_inline)) {
@@ -250,8 +324,8 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             float16v st[2];
             st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qfr, zero16, 0, 0, 0);
             st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qfr, zero16, 0, 0, 0);
-            // the bias (older than the two pieces issued after it); the operands tie the registers to this point
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(bias8[0]), "+v"(bias8[1]), "+v"(bias8[2]), "+v"(bias8[3]) :: "memory");
+            // the bias and every piece issued before it (those landed long ago); the operands tie the registers to this point
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias8[0]), "+v"(bias8[1]), "+v"(bias8[2]), "+v"(bias8[3]) :: "memory");
             float e[2][16];
             float su = 0.f, sm = 0.f;
             static_for<0, 2>([&](auto kt_) __attribute__((always_inline)) {
@@ -263,7 +337,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                     const float eu = __builtin_amdgcn_exp2f(d);
                     e[kt][r] = eu;
                     su += eu;
-                    sm += eu * visf[bi];
+                    sm += eu * (float)visp[bi >> 1][bi & 1];
                 });
             });
             su += __shfl_xor(su, 32);
@@ -277,7 +351,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                     static_for<0, 8>([&](auto u_) __attribute__((always_inline)) {
                         constexpr int u = decltype(u_)::value;
                         constexpr int r = 8 * jb + u, bi = kt * 16 + r;
-                        const float vis = visf[bi];
+                        const float vis = (float)visp[bi >> 1][bi & 1];
                         pf[u] = (_Float16)(e[kt][r] * (vis * cm + cu));
                     });
                     oacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kt][jb], pf, oacc, 0, 0, 0);
@@ -297,24 +371,22 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             asm volatile("ds_write_b128 %0, %1" :: "v"((uint32_t)(uintptr_t)Qp), "v"(ov) : "memory");
         }
         if (g == 5) AB_ST(7);
-        // ---- 3. proj accumulate: two pieces of 160 output channels
-        half8 of;
-        static_for<0, 2>([&](auto hh_) __attribute__((always_inline)) {
-            constexpr int hh = decltype(hh_)::value;
-            if constexpr (hh == 1) AB_WAIT(4);
-            else AB_LGKM0();                                  // this wave's O rows are in LDS
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            issue(t0 + 5 + hh + 3);
-            if constexpr (hh == 0)
-                of = *reinterpret_cast<const half8*>(smem + AB_QK + (lq >> 1) * 4096 + (16 * w + l15) * 32 + (lq & 1) * 16);
-            const char* pb = ring + ((t0 + 5 + hh) & 3) * AB_PIECE + wpo;
-            static_for<0, 10>([&](auto jj_) __attribute__((always_inline)) {
-                constexpr int jj = decltype(jj_)::value;
-                const half8 wf = *reinterpret_cast<const half8*>(pb + jj * 1024);
-                oc[10 * hh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, of, oc[10 * hh + jj], 0, 0, 0);
-            });
-        });
+    };
+
+    // qkv of group 0 | 9 x (attention of group g, then proj of g and qkv of g + 1 as one sequence) | attention and proj of group 9
+    if (AB_DBG != 1) {
+        zero_qa();
+        sequence(std::false_type{}, std::true_type{}, 0, 0);
+#pragma unroll 1
+        for (int g = 0; g < AB_GROUPS - 1; ++g) {
+            stage_and_attend(g);
+            if (g == 4) AB_ST(8);
+            if (g == 5) AB_ST(11);
+            zero_qa();
+            sequence(std::true_type{}, std::true_type{}, 7 * g + 5, g + 1);
+        }
+        stage_and_attend(AB_GROUPS - 1);
+        sequence(std::true_type{}, std::false_type{}, 7 * AB_GROUPS - 2, AB_GROUPS);
     }
     AB_ST(2);
     // every wave's DMA (the three pad pieces included) has landed and every wave has left the ring before it is reused

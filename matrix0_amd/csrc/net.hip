@@ -196,7 +196,7 @@ int Net::pack_attn_block(AttnW& a, const std::string& prefix, std::string& err) 
             const size_t base = (size_t)(g * 7 + 5 + hh) * 6144;
             for (int cl = 0; cl < 160; ++cl)
                 for (int k = 0; k < 32; ++k) {
-                    const int pos = (k >> 3) ^ ((cl >> 2) & 3);
+                    const int pos = (k >> 3) ^ ((4 - ((cl >> 2) & 3)) & 3);
                     buf[base + (size_t)cl * 32 + pos * 8 + (k & 7)] = (_Float16)proj_w(160 * hh + cl, 2 * g + (k >> 4), k & 15);
                 }
         }
