@@ -34,7 +34,9 @@ constexpr int AB_PIECE = 12288;
 constexpr int AB_PIECES_PER_GROUP = 7;
 constexpr int AB_GROUPS = 10;
 constexpr int AB_X = 0;                                   // [128][640 B], 16-byte chunk ^ (row>>1)&7 within 128 B
-constexpr int AB_QK = 81920;                              // Q [2][128][16] | K [2][128][16]   (O overlays Q)
+constexpr int AB_QK = 81920;                              // Q [2][128][16] | K [2][128][16]   (O overlays Q); a token's two 16-byte
+                                                          // halves are stored at half ^ (token >> 3 & 1): conflict-free ds_read_b128 of
+                                                          // 32 consecutive tokens, the staging's 8-byte writes 2-way instead of 4-way
 constexpr int AB_VT = AB_QK + 16384;                      // [4 units][16][68]
 constexpr int AB_VROW = 68;
 constexpr int AB_RING = AB_VT + 4 * 16 * AB_VROW * 2;     // 107008
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     // quad of lq = 0 / 2 next to two of lq = 1 / 3): chunk ^ (4 - quad) & 3 gives the 16 lanes of a group 16 different bank quads
     const int wpo = l15 * 64 + ((lq ^ (4 - (l15 >> 2))) & 3) * 16;
     const uint32_t ring_a = lds0 + AB_RING;
-    const uint32_t of_a = lds0 + AB_QK + (lq >> 1) * 4096 + (16 * w + l15) * 32 + (lq & 1) * 16;   // this wave's O rows (proj operand)
+    const uint32_t of_a = lds0 + AB_QK + (lq >> 1) * 4096 + (16 * w + l15) * 32 + ((lq & 1) ^ (l15 >> 3)) * 16;   // this wave's O rows (proj operand)
 
     const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
     const float16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                 const int token = 32 * wm + 16 * i + l15;
                 const half4v h = {(_Float16)qa[i][j][0], (_Float16)qa[i][j][1], (_Float16)qa[i][j][2], (_Float16)qa[i][j][3]};
                 if (type < 2) {
-                    *reinterpret_cast<half4v*>(smem + AB_QK + type * 8192 + hl * 4096 + token * 32 + lq * 8) = h;
+                    *reinterpret_cast<half4v*>(smem + AB_QK + type * 8192 + hl * 4096 + token * 32 + (((lq >> 1) ^ (l15 >> 3)) & 1) * 16 + (lq & 1) * 8) = h;
                 } else {
                     const int unit = (token >> 6) * 2 + hl, sq = token & 63;
                     _Float16* vt = reinterpret_cast<_Float16*>(smem + AB_VT) + (unit * 16 + 4 * lq) * AB_VROW + sq;
@@ -305,9 +307,10 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         // ---- 2. attention of this wave's (board, head, query half)
         if (AB_DBG != 2) {
             const char* Kb = smem + AB_QK + 8192 + ahl * 4096 + aboard * 64 * 32;
-            const half8 kf0 = *reinterpret_cast<const half8*>(Kb + r31 * 32 + 16 * half);
-            const half8 kf1 = *reinterpret_cast<const half8*>(Kb + (32 + r31) * 32 + 16 * half);
-            char* Qp = smem + AB_QK + ahl * 4096 + (aboard * 64 + aq) * 32 + 16 * half;      // also where O goes
+            const int hsw = 16 * (half ^ ((r31 >> 3) & 1));                                     // this lane's half of its token's row
+            const half8 kf0 = *reinterpret_cast<const half8*>(Kb + r31 * 32 + hsw);
+            const half8 kf1 = *reinterpret_cast<const half8*>(Kb + (32 + r31) * 32 + hsw);
+            char* Qp = smem + AB_QK + ahl * 4096 + (aboard * 64 + aq) * 32 + hsw;            // also where O goes
             const half8 qfr = *reinterpret_cast<const half8*>(Qp);
             half8 vf[2][2];
             {
