@@ -83,13 +83,27 @@ __device__ __forceinline__ float ab_row_sum(float v) {
 #define AB_DBG 0
 #endif
 #define AB_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#ifdef AB_STAMP
+#if defined(AB_STAMP) || defined(AB_STAMP2) || defined(AB_STAMP3)
 __device__ unsigned long long* g_ab_stamp;        // [blocks][16] s_memtime stamps of wave 0 (tools/ubench/attn_block_bench.hip)
+#ifdef AB_STAMP
 #define AB_ST(k) do { if (tid == 0) g_ab_stamp[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AB_ST(k) do {} while (0)
 #endif
+#else
+#define AB_ST(k) do {} while (0)
+#endif
 #define AB_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef AB_STAMP3      // ten stamps inside ONE piece (piece 3 of group 5's sequence), same mechanism as AB_STAMP2
+#define AB_T3(k) do { if (g == 5) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_T3(k) do {} while (0)
+#endif
+#ifdef AB_STAMP2      // stamps kept in scalar registers and stored at the end of the kernel (waves 0 and 4): no store, no wait at the stamp
+#define AB_TS(k) do { if (g == 5) ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AB_TS(k) do {} while (0)
+#endif
 
 template <int ACT>
 __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
@@ -192,6 +206,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
     // front of their own (both waves of a SIMD sit at the same barrier: nothing else would overlap them).  Per piece
     // boundary: this wave's reads of piece i are complete (lgkmcnt) and its parts of piece i+1 have landed (vmcnt) ->
     // barrier -> read the first half of piece i+1 -> DMA piece i+4 into the slot of piece i -> MFMAs of the last half of i.
+#if defined(AB_STAMP2) || defined(AB_STAMP3)
+    unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     half8 fs[2][5];
     half8 of;
     float4v qa[2][3];
@@ -243,25 +260,36 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                 });
             }
         };
+        if constexpr (HP && HQ) AB_TS(0);
         AB_LGKM0();                                           // this wave's O rows of the previous group are in LDS
         AB_WAIT(4);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (HP && HQ) AB_TS(1);
         load(std::integral_constant<int, 0>{});
         issue(T + 3);
         static_for<0, NU>([&](auto u_) __attribute__((always_inline)) {
             constexpr int u = decltype(u_)::value;
             if constexpr (u + 1 < NU) {
                 if constexpr (u & 1) {
+                    if constexpr (HP && HQ && u == 7) AB_T3(7);
                     arrived(u_, std::integral_constant<int, 0>{});
+                    if constexpr (HP && HQ && u == 7) AB_T3(8);
                     AB_WAIT(4);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    if constexpr (HP && HQ && u == 5) AB_T3(0);
+                    if constexpr (HP && HQ && u == 7) AB_T3(9);
                     if constexpr (HP && HQ && (u == 1 || u == 3 || u == 7 || u == 11)) { if (g == 5) AB_ST(u == 1 ? 12 : u == 3 ? 13 : u == 7 ? 14 : 15); }
+                    if constexpr (HP && HQ) AB_TS(2 + (u >> 1));
                 }
                 load(std::integral_constant<int, u + 1>{});
+                if constexpr (HP && HQ && u == 5) AB_T3(1);
+                if constexpr (HP && HQ && u == 6) AB_T3(4);
                 if constexpr (u & 1) issue(T + (u >> 1) + 4);
                 else arrived(u_, std::integral_constant<int, 5>{});
+                if constexpr (HP && HQ && u == 5) AB_T3(2);
+                if constexpr (HP && HQ && u == 6) AB_T3(5);
             } else {
                 arrived(u_, std::integral_constant<int, 0>{});
             }
@@ -274,6 +302,9 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
             }
             mma(u_);
             __builtin_amdgcn_sched_barrier(0);                // the next half's wait stays behind these MFMAs
+            if constexpr (HP && HQ && u == 5) AB_T3(3);
+            if constexpr (HP && HQ && u == 6) AB_T3(6);
+            if constexpr (HP && HQ && u == NU - 1) AB_TS(8);
         });
     };
 
@@ -304,6 +335,7 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (g == 5) AB_ST(6);
+        AB_TS(9);
         // ---- 2. attention of this wave's (board, head, query half)
         if (AB_DBG != 2) {
             const char* Kb = smem + AB_QK + 8192 + ahl * 4096 + aboard * 64 * 32;
@@ -392,6 +424,10 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
         sequence(std::true_type{}, std::false_type{}, 7 * AB_GROUPS - 2, AB_GROUPS);
     }
     AB_ST(2);
+#if defined(AB_STAMP2) || defined(AB_STAMP3)
+    if (lane == 0 && (w & 3) == 0)
+        for (int k = 0; k < 10; ++k) g_ab_stamp[((size_t)blockIdx.x * 2 + (w >> 2)) * 16 + k] = ts[k];
+#endif
     // every wave's DMA (the three pad pieces included) has landed and every wave has left the ring before it is reused
     AB_WAIT(0);
     __syncthreads();

@@ -86,8 +86,8 @@ int main(int argc, char** argv) {
     a.x = dx; a.wpack = dw; a.bias = dbb; a.mask = dm; a.ln_g = dlg; a.ln_b = dlb; a.gn2_gamma = dg2; a.gn2_beta = db2;
     a.y = dy; a.y2 = dy2; a.B = boards; a.ln_count = C; a.act = ACT_SILU; a.mix = 0.3f; a.inv_sqrt_d = 0.25f;
     hipStream_t st; hipStreamCreate(&st);
-#ifdef AB_STAMP
-    unsigned long long* dst_ab; hipMalloc(&dst_ab, (size_t)(boards / 2) * 16 * 8); hipMemset(dst_ab, 0, (size_t)(boards / 2) * 16 * 8);
+#if defined(AB_STAMP) || defined(AB_STAMP2) || defined(AB_STAMP3)
+    unsigned long long* dst_ab; hipMalloc(&dst_ab, (size_t)(boards / 2) * 32 * 8); hipMemset(dst_ab, 0, (size_t)(boards / 2) * 32 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_ab_stamp), &dst_ab, sizeof(dst_ab));
 #endif
     hipError_t e = launch_attn_block(a, st);
@@ -224,6 +224,47 @@ int main(int argc, char** argv) {
             std::sort(d.begin(), d.end());
             printf("  %-40s median %8.0f cycles\n", names[k], d[d.size() / 2]);
         }
+    }
+#endif
+#ifdef AB_STAMP3
+    {   // ten register-held stamps inside piece 3 (a qkv piece) of group 5's sequence, waves 0 and 4
+        const int nb2 = boards / 2;
+        std::vector<unsigned long long> hs((size_t)nb2 * 32);
+        hipMemcpy(hs.data(), dst_ab, hs.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[] = {"barrier passed -> 5 reads of the next half issued", "2 DMA instructions issued", "MFMAs of the first half issued (6)",
+                               "5 reads of the next piece's first half issued", "lgkmcnt(5): this half's fragments there", "MFMAs of the second half issued (6)",
+                               "(to the boundary)", "lgkmcnt(0)", "vmcnt(4) + barrier passed"};
+        for (int wv = 0; wv < 2; ++wv) {
+            printf(" wave %d:\n", 4 * wv);
+            for (int k = 0; k < 9; ++k) {
+                std::vector<double> d;
+                for (int b = 0; b < nb2; ++b) d.push_back((double)(hs[((size_t)b * 2 + wv) * 16 + k + 1] - hs[((size_t)b * 2 + wv) * 16 + k]));
+                std::sort(d.begin(), d.end());
+                printf("  %-52s median %6.0f  (10 %% %6.0f, 90 %% %6.0f) cycles\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+            }
+        }
+    }
+#endif
+#ifdef AB_STAMP2
+    {   // register-held stamps of the sequence "proj of group 4 + qkv of group 5" and the staging after it, waves 0 and 4 of every workgroup
+        const int nb2 = boards / 2;
+        std::vector<unsigned long long> hs((size_t)nb2 * 32);
+        hipMemcpy(hs.data(), dst_ab, hs.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[] = {"entry -> start barrier passed", "piece 0 (proj): barrier -> barrier", "piece 1 (proj)", "piece 2 (qkv)", "piece 3 (qkv)",
+                               "piece 4 (qkv)", "piece 5 (qkv)", "piece 6 (qkv): barrier -> last MFMA issued", "staging: -> barrier passed"};
+        for (int wv = 0; wv < 2; ++wv) {
+            printf(" wave %d:\n", 4 * wv);
+            for (int k = 0; k < 9; ++k) {
+                std::vector<double> d;
+                for (int b = 0; b < nb2; ++b) d.push_back((double)(hs[((size_t)b * 2 + wv) * 16 + k + 1] - hs[((size_t)b * 2 + wv) * 16 + k]));
+                std::sort(d.begin(), d.end());
+                printf("  %-45s median %7.0f  (10 %% %7.0f, 90 %% %7.0f) cycles\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+            }
+        }
+        std::vector<double> sk;      // skew: wave 4's entry minus wave 0's
+        for (int b = 0; b < nb2; ++b) sk.push_back((double)hs[((size_t)b * 2 + 1) * 16] - (double)hs[((size_t)b * 2) * 16]);
+        std::sort(sk.begin(), sk.end());
+        printf(" entry of wave 4 minus entry of wave 0: median %.0f (10 %% %.0f, 90 %% %.0f)\n", sk[sk.size() / 2], sk[sk.size() / 10], sk[sk.size() * 9 / 10]);
     }
 #endif
     printf("attn_block boards %d: %.1f us / launch, %.3f PFLOP/s, %.2f TB/s (x + y + y2)\n", boards, us, flop / us * 1e-9,
