@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
                     constexpr int ni = decltype(ni_)::value;
                     fb[ni] = *reinterpret_cast<const half8*>(Wb + ni * 1024);
                 });
+                P16_FENCE(); issue_next(G_); P16_FENCE();      // in the load section, not between the MFMAs (conv_zs.hip)
                 asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 P16_FENCE();
                 __builtin_amdgcn_s_barrier();
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(512) void conv_pp16_kernel(GemmArgs a) {
                         constexpr int mi = decltype(mi_)::value;
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
                     });
-                    if constexpr (ni == 2) { P16_FENCE(); issue_next(G_); P16_FENCE(); }
                 });
                 __builtin_amdgcn_s_setprio(0);
                 P16_FENCE();

@@ -186,6 +186,14 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
                         constexpr int ni = decltype(ni_)::value;
                         fb[ni] = *reinterpret_cast<const half8*>(Wb + ni * 1024);
                     });
+                    // This wave's share of the half-tile three ahead goes out HERE, in the load section (which has ~300 cycles of slack
+                    // under the partner group's 40 MFMAs), not between this wave's own MFMAs: an LDS-DMA instruction takes 40-60
+                    // cycles to issue, and in the compute section the SIMD's matrix pipe idles for them (three per half-tile: the
+                    // main loop was 127.4 k cycles per tile with the DMA after the second channel tile's MFMAs, 113.4 k here; the
+                    // chip gives part of it back as clock, 1.81 -> 1.71 GHz: -4 % wall).  The slot's previous tenant (the
+                    // half-tile before this one) was read into registers by both wave groups at least a phase ago.
+                    ZS_FENCE(); issue_next(G_); ZS_FENCE();
+                    // all but this wave's three youngest pieces (the ones just issued) have landed
                     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     ZS_FENCE();
                     __builtin_amdgcn_s_barrier();
@@ -202,7 +210,6 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
                             else
                                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
                         });
-                        if constexpr (ni == 1) { ZS_FENCE(); issue_next(G_); ZS_FENCE(); }
                     });
                     __builtin_amdgcn_s_setprio(0);
                     ZS_FENCE();
