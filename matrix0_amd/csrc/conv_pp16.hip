@@ -4,8 +4,9 @@
 // Why the shape matters: the main loop is POWER-bound, not issue-bound.  In-kernel stamps (tools/ubench, -DSW_STAMP, random
 // operands) show the 32x32x16 loop at 87.7 % of the MFMA issue rate but at an in-kernel clock of 1.52-1.57 GHz; the same
 // loop on 16x16x32 spends more cycles (82 %) at 1.75-1.82 GHz and finishes 5.6-7 % sooner (MI355X_MICROARCH.md, DVFS
-// give-back item 7: the chip holds a higher clock on this shape).  Cycle savings on either loop (DMA placement, early
-// barriers, static priority) leave the wall time unchanged -- the clock falls as the MFMAs pack closer.
+// give-back item 7: the chip holds a higher clock on this shape).  Small cycle savings on either loop (DMA placement inside
+// the compute section, early barriers, static priority) left the wall time unchanged in round 2 -- the clock falls as the MFMAs
+// pack closer; round 3's move of the DMA out of the compute section altogether (-11 % cycles, conv_zs.hip) came back as -4 % wall.
 //
 // One phase pair per half-tile (32 k): a wave reads 4 activation fragments (16 squares x 32 k each) and 10 weight fragments
 // (16 channels x 32 k), then issues 40 MFMAs; accumulators = 4 x 10 tiles of 16 squares x 16 channels (160 registers).
