@@ -208,6 +208,42 @@ int main(int argc, char** argv) {
                d[0] / nb * 0.01, d[1] / nb * 0.01, d[2] / nb * 0.01, d[3] / nb * 0.01);
     }
 #endif
+#if defined(SW_STAMP) && defined(BENCH_ZS)
+    {   // per-CU timeline of the last launch of conv_zs_kernel: entry -> loop start -> loop end -> exit (after the epilogue), 10-ns ticks
+        const int nb = M / 256;
+        std::vector<unsigned long long> hs((size_t)nb * 8);
+        hipMemcpy(hs.data(), dst_, hs.size() * 8, hipMemcpyDeviceToHost);
+        struct Ev { unsigned long long entry, ls, le, x; };
+        std::map<unsigned long long, std::vector<Ev>> bycu;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < nb; ++b) {
+            Ev e{hs[(size_t)nb * 4 + b * 4 + 0], hs[b * 4 + 1], hs[b * 4 + 3], hs[(size_t)nb * 4 + b * 4 + 1]};
+            const unsigned long long id = (hs[(size_t)nb * 4 + b * 4 + 3] << 32) | (hs[(size_t)nb * 4 + b * 4 + 2] & 0xffffff00ull);
+            bycu[id].push_back(e);
+            t0 = std::min(t0, e.entry); t1 = std::max(t1, e.x);
+        }
+        double pro = 0, loop = 0, epi = 0, gap = 0; int ng = 0, n = 0;
+        std::vector<double> busy, first, last, cnt;
+        for (auto& kv : bycu) {
+            auto& v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Ev& a, const Ev& b) { return a.entry < b.entry; });
+            double bsum = 0;
+            for (size_t i = 0; i < v.size(); ++i) {
+                pro += (double)(v[i].ls - v[i].entry); loop += (double)(v[i].le - v[i].ls); epi += (double)(v[i].x - v[i].le); ++n;
+                bsum += (double)(v[i].x - v[i].entry);
+                if (i) { gap += (double)(v[i].entry - v[i - 1].x); ++ng; }
+            }
+            busy.push_back(bsum * 0.01); first.push_back((double)(v.front().entry - t0) * 0.01); last.push_back((double)(t1 - v.back().x) * 0.01);
+            cnt.push_back((double)v.size());
+        }
+        std::sort(first.begin(), first.end()); std::sort(last.begin(), last.end()); std::sort(cnt.begin(), cnt.end()); std::sort(busy.begin(), busy.end());
+        printf("timeline: %zu CU ids, span %.1f us; per workgroup: prologue %.2f us, main loop %.2f us, epilogue %.2f us; gap exit->next entry %.2f us (n=%d)\n",
+               bycu.size(), (t1 - t0) * 0.01, pro / n * 0.01, loop / n * 0.01, epi / n * 0.01, ng ? gap / ng * 0.01 : 0.0, ng);
+        printf("  per CU: tiles min %.0f median %.0f max %.0f; busy us min %.1f median %.1f max %.1f; first entry after launch start: median %.1f max %.1f us; idle at the end: median %.1f max %.1f us\n",
+               cnt.front(), cnt[cnt.size() / 2], cnt.back(), busy.front(), busy[busy.size() / 2], busy.back(), first[first.size() / 2], first.back(),
+               last[last.size() / 2], last.back());
+    }
+#endif
 #if defined(SW_STAMP) && defined(BENCH_P16)
     {   // per-CU timeline of the last launch: entry -> loop start -> loop end -> (before epilogue), realtime ticks of 10 ns
         const int nb = M / 256;
