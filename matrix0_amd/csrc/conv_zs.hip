@@ -49,43 +49,32 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     char* Z_lds = smem + ZS_OFF_Z;
     char* D_lds = smem + ZS_OFF_D;
 
+#ifdef SW_STAMP
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3;              // channel quarter
     const int wp = wave >> 2;             // board pair of the tile = ping-pong group
+    const int m0 = blockIdx.x * 256;
     const int n0 = blockIdx.y * 320;
     const int Cin = a.Cin;
     const int nchunk = Cin >> 6;
     const int NH = nchunk * 18;           // half-tiles
-    const int ntiles = a.Mrows >> 8;
-
-    // PERSISTENT: the launch puts one workgroup on every CU (launch_conv_zs_e) and a workgroup walks the tiles blockIdx.x,
-    // blockIdx.x + gridDim.x, ...  Handing a CU to a NEW 160-KB workgroup costs 2.8 us per tile (all 8 waves gone, LDS released,
-    // dispatch, kernel arguments: per-CU timeline, tools/ubench/conv_pp_bench.hip -DSW_STAMP); the loop's own turnover is one barrier.
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#ifdef SW_STAMP
-    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
-#endif
-    const int m0 = tile * 256;
+    const int c15 = lane & 15;
+    const int q = lane >> 4;
 
     reinterpret_cast<uint4*>(Z_lds)[tid] = make_uint4(0, 0, 0, 0);          // 512 x 16 B = the whole zero region
 
-    // (the prologue's per-lane source addresses are tile-invariant too: an opaque copy of the lane number keeps them out of the
-    // registers that live through the main loop -- see the epilogue call below)
-    int plane = lane;
-    asm volatile("" : "+v"(plane));
-    const int c15 = plane & 15;
-    const int q = plane >> 4;
     const char* in_bytes = reinterpret_cast<const char*>(a.in);
-    const char* w_blk = reinterpret_cast<const char*>(a.w) + (size_t)blockIdx.y * (2 * ZS_WH_BYTES) + plane * 16;
+    const char* w_blk = reinterpret_cast<const char*>(a.w) + (size_t)blockIdx.y * (2 * ZS_WH_BYTES) + lane * 16;
     const size_t w_kt_stride = (size_t)gridDim.y * (2 * ZS_WH_BYTES);
 
     auto issue_A_piece = [&](int chunk, int qq) __attribute__((always_inline)) {
-        const int p = 8 * qq + (plane >> 3);            // 1-KiB piece: rows 8qq..8qq+7 of the 256-row tile
+        const int p = 8 * qq + (lane >> 3);             // 1-KiB piece: rows 8qq..8qq+7 of the 256-row tile
         const int key = (p & 2) | (((p >> 6) & 1) << 2);
-        const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * ((plane & 7) ^ key);
+        const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * ((lane & 7) ^ key);
         zs_glds16(src, A_lds + (chunk & 1) * ZS_A_BYTES + qq * 1024);
     };
     auto issue_half = [&](int y) __attribute__((always_inline)) {      // prologue only
@@ -124,10 +113,10 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     if (wp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
     // ---- steady-state DMA (wave-uniform state, advanced incrementally; see tools/ubench/conv_pp.hip) ----
-    const uint32_t w_lane = (uint32_t)plane * 16u;
+    const uint32_t w_lane = (uint32_t)lane * 16u;
     // activation piece qq = 4 xi + wave - 4 (xi = 0..7): rows 32 xi + 8 (wave - 4) + (lane >> 3); key = ((lane >> 3) & 2) | (xi & 2) << 1
-    const uint32_t a_lane0 = (uint32_t)(plane >> 3) * (uint32_t)Cin * 2u + 16u * (uint32_t)((plane & 7) ^ ((plane >> 3) & 2));
-    const uint32_t a_lane1 = (uint32_t)(plane >> 3) * (uint32_t)Cin * 2u + 16u * (uint32_t)((plane & 7) ^ (((plane >> 3) & 2) | 4));
+    const uint32_t a_lane0 = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + 16u * (uint32_t)((lane & 7) ^ ((lane >> 3) & 2));
+    const uint32_t a_lane1 = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + 16u * (uint32_t)((lane & 7) ^ (((lane >> 3) & 2) | 4));
     const char* w_base = reinterpret_cast<const char*>(a.w) + (size_t)blockIdx.y * (2 * ZS_WH_BYTES) + wave * 1024;  // uniform
     int t_next = 3;
     const char* w_ptr = w_base + (size_t)1 * w_kt_stride + ZS_WH_BYTES;     // half-tile 3 = K-tile 1, half 1
@@ -239,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     else main_loop(std::integral_constant<int, 1>{});
 #ifdef SW_STAMP
     if (tid == 0) {
-        unsigned long long* o = g_zs_stamp + (size_t)tile * 4;
+        unsigned long long* o = g_zs_stamp + (size_t)blockIdx.x * 4;
         o[0] = st_c0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
@@ -253,32 +242,18 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NG; ++ni) asm volatile("" :: "v"(acc[mi][ni]));
 #else
-    {
-        // the epilogue's per-lane constants (addresses, GroupNorm parameters) are the same for every tile; opaque copies of the lane and
-        // wave numbers keep hipcc from computing them once before the tile loop and carrying them through the main loop, where the
-        // 160 accumulator + 52 fragment registers leave no room (83-120 spilled registers otherwise)
-        int elane = lane, ewave = wave;
-        asm volatile("" : "+v"(elane));
-        asm volatile("" : "+s"(ewave));
-        const int ewn = ewave & 3, ewp = ewave >> 2;
-        if constexpr (EPI == 3) zs_tail_epilogue<ACT, false>(acc, a, smem, m0, ewp, ewn, ewave, elane);
-        else if constexpr (EPI == 5) zs_tail_epilogue<ACT, true>(acc, a, smem, m0, ewp, ewn, ewave, elane);
-        else zs_tile_epilogue<EPI, ACT>(acc, a, smem + ewave * 20480, m0, n0, ewp, ewn, elane);
-    }
+    if constexpr (EPI == 3) zs_tail_epilogue<ACT, false>(acc, a, smem, m0, wp, wn, wave, lane);
+    else if constexpr (EPI == 5) zs_tail_epilogue<ACT, true>(acc, a, smem, m0, wp, wn, wave, lane);
+    else zs_tile_epilogue<EPI, ACT>(acc, a, smem + wave * 20480, m0, n0, wp, wn, lane);
 #endif
-#ifdef SW_STAMP     // timeline of the workgroup (10-ns ticks) and where it ran: [blocks][4] behind the main-loop stamps
+#ifdef SW_STAMP     // timeline of the workgroup (10-ns ticks, wave 0) and where it ran: [blocks][4] behind the main-loop stamps
     if (tid == 0) {
-        unsigned long long* o = g_zs_stamp + (size_t)ntiles * 4 + (size_t)tile * 4;
+        unsigned long long* o = g_zs_stamp + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         o[0] = st_entry; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = hw; o[3] = xcc;
     }
 #endif
-    // every wave has left the LDS (staging images, pools) before the next tile's zero region and DMA pieces are written; the
-    // epilogue's global stores stay in flight (raw barrier: __syncthreads() would wait for them)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    }
 }
 
 template <int EPI, int ACT>
@@ -290,16 +265,7 @@ static hipError_t launch_conv_zs_e(const GemmArgs& a, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (e != hipSuccess) return e;
-    // one workgroup per CU (160 KB of LDS each: they cannot share one), walking the tiles
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    const int ntiles = a.Mrows / 256, ny = a.Npad / 320;
-#ifdef ZS_NO_PERSIST
-    dim3 grid(ntiles, ny);
-#else
-    dim3 grid(ntiles < cus / ny ? ntiles : (cus / ny > 0 ? cus / ny : 1), ny);
-#endif
+    dim3 grid(a.Mrows / 256, a.Npad / 320);
     hipLaunchKernelGGL((conv_zs_kernel<EPI, ACT>), grid, dim3(512), lds, st, a);
     return hipGetLastError();
 }
