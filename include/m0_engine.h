@@ -179,7 +179,9 @@ typedef struct m0_selfplay_cfg {
     /* per-game evaluation cache (csrc/tree.h EvalCache): a leaf whose position was evaluated before -- a transposition inside
      * the search, a position of a discarded subtree -- is expanded from the stored value + legal logits instead of going
      * through the network again.  Games are unchanged (the forward is bitwise batch invariant on the 320-wide path).  Active
-     * only with legal_softmax = 1 and without tt_merge / raw_legal_priors.  0 = off. */
+     * only with legal_softmax = 1 and without tt_merge / raw_legal_priors, and never in a match engine (m0_arena_create*:
+     * two networks alternate in one game slot and the key carries no network id -- the field is ignored there).  A hit must
+     * also match the stored legal-move count and a checksum of the legal moves; otherwise it is served as a miss.  0 = off. */
     int eval_cache;
     int eval_cache_entries;       /* entries per game (rounded up to a power of two, 4-way sets); 0 = 16384 */
 } m0_selfplay_cfg;

@@ -25,6 +25,12 @@ struct DeviceOnce {
     }
 };
 
+// RULE for every kernel that stages through LDS-DMA (__builtin_amdgcn_global_load_lds: conv_zs / conv_pp16 / attn_block /
+// conv_big): a COUNTED `s_waitcnt vmcnt(N)` (N > 0) may only be used while nothing but LDS-DMA operations of this wave is
+// outstanding.  vmcnt counts loads into registers, stores and LDS-DMA together, but a later LDS-DMA can retire before an
+// earlier load into registers (measured on gfx950, round 3: `vmcnt(1)` meant as "the bias load, not the DMA after it" let
+// waves read their bias registers early; 17-89 of 24 576 boards differed from run to run).  So: issue register loads after
+// the last counted wait of a sequence and wait for them with vmcnt(0), or keep them out of the DMA window altogether.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 

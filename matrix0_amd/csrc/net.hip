@@ -479,9 +479,13 @@ int Net::ensure_workspace(int B, std::string& err) {
         wsB_ = wsM_ = 0;
         return M0_ERR_HIP;
     }
-    // the clears were enqueued on stream_, the stream every forward of this network runs on: ordered before the first kernel
-    // (tests/test_net_gpu.py::test_workspace_regrowth_keeps_results)
-    if (hipGetLastError() != hipSuccess) { err = "workspace clear failed"; wsB_ = wsM_ = 0; return M0_ERR_HIP; }
+    // The clears were enqueued on stream_.  A forward may run on ANOTHER stream (the match engine runs network B on network
+    // A's stream, selfplay.hip::one_step), so the (rare) regrowth ends by waiting for them: a late clear would zero
+    // activations a kernel already wrote.  The wait also surfaces an asynchronous memset failure.
+    // (tests/test_net_gpu.py::test_workspace_regrowth_keeps_results, tests/test_arena_gpu.py::test_step_right_after_create)
+    if (hipStreamSynchronize(stream_) != hipSuccess || hipGetLastError() != hipSuccess) {
+        err = "workspace clear failed"; wsB_ = wsM_ = 0; return M0_ERR_HIP;
+    }
     wsB_ = Bp; wsM_ = Mfc;
     return M0_OK;
 }

@@ -577,6 +577,9 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->net = m0_net_impl(nh);
     sp->net_b = m0_net_impl(nh_b);
     sp->cfg.arena_mode = (nh_b || arena) ? 1 : 0;
+    // A match engine alternates two networks in one game slot and the cache key covers the position only (no network id):
+    // side B's leaves would be expanded from side A's cached value and logits.  Off, whatever the caller asked for.
+    if (sp->cfg.arena_mode) { sp->cfg.eval_cache = 0; sp->tc.eval_cache = 0; }
     sp->device = nh ? m0_net_device(nh) : 0;
     if (nh && (unsigned)sp->device < (unsigned)M0_MAX_DEVICES) { g_engines_with_net[sp->device].fetch_add(1); sp->counted = true; }
     (void)hipSetDevice(sp->device);

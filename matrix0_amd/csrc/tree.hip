@@ -304,6 +304,17 @@ __device__ void apply_dirichlet(const Arena& A, int root, GameDev* gd, const Tre
     __syncthreads();
 }
 
+// What an evaluation-cache entry stands for besides its 64-bit key: the legal-move count (low 8 bits; cacheable positions have
+// at most M0_EC_MAXLEGAL = 64 moves, one per lane) and a 24-bit checksum of the legal moves in order.  A hit whose signature
+// differs is a key collision and is treated as a miss: the payload's logits are stored in legal-move order, so serving them
+// to another move list would expand the node with wrong priors without any other symptom.
+__device__ __forceinline__ int legal_sig(const Move* mv, int n, int lane) {
+    uint32_t h = lane < n ? ((uint32_t)mv[lane] + 1u) * 0x9E3779B1u + (uint32_t)lane * 0x85EBCA6Bu : 0u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+    for (int o = 32; o > 0; o >>= 1) h ^= (uint32_t)__shfl_xor((int)h, o);
+    return n | (int)(h & 0xFFFFFF00u);
+}
+
 // table of game g (of its side gd->arena in a match engine with per-side tables)
 __device__ __forceinline__ size_t tt_table_of(const TreeDev& d, int g, const GameDev* gd) {
     return ((size_t)g * d.tt_sides + (d.tt_sides == 2 ? gd->arena : 0)) * (size_t)d.tt_cap;
@@ -484,8 +495,8 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
                 const float* src = d.ec.payload + (eb + way) * M0_EC_WORDS;
                 float* dst = d.ec.hit_stage + ((size_t)g * (d.L + 1) + s) * M0_EC_WORDS;
                 for (int i = lane; i < M0_EC_WORDS; i += 64) dst[i] = src[i];
-                // the legal-move count must agree (it is part of what the key stands for): a mismatch = a key collision
-                cached = __float_as_int(src[1]) == nlegal;
+                // the legal moves must agree (count and checksum: legal_sig): a mismatch = a key collision, served as a miss
+                cached = __float_as_int(src[1]) == legal_sig(smoves, nlegal, lane);
                 if (cached && lane == 0) { d.ec.stamps[eb + way] = ++gd->cache_clock; }
             }
         }
@@ -802,9 +813,10 @@ __global__ __launch_bounds__(64) void expand_kernel(TreeDev d, TreeCfg c) {
                                             kind == 2, &X, TK, TN, d.tt_cap, !(kind == 2 && gd->root_fresh), nullptr, cw);
                 // an expansion that did not happen (node arena exhausted) must not leave the pending-row mark behind
                 if (c.eval_cache && kind == 1 && lane == 0 && A.nch[leaf] < 0) A.cbase[leaf] = -1;
+                const int sig = cw ? legal_sig(LM + (size_t)s * M0_MAX_CHILDREN, S[s].nlegal, lane) : 0;
                 if (cw && lane == 0) {
                     if (ok && !X.bad) {
-                        cw[0] = v; cw[1] = __int_as_float(S[s].nlegal);
+                        cw[0] = v; cw[1] = __int_as_float(sig);
                         __threadfence_block();
                         d.ec.keys[ce] = ckey; d.ec.stamps[ce] = ++gd->cache_clock;
                     }

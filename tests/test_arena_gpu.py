@@ -140,3 +140,37 @@ def test_per_side_tables_start_over_when_their_arena_is_full():
         _replay(r, 30)
         assert len(r["played"]) >= 20                    # no search ended without visits (that would end the game early)
     a.close(); b.close()
+
+
+def test_step_right_after_create_and_eval_cache_ignored_by_the_match_engine():
+    """(a) Network B's forward runs on network A's stream: its workspace (allocated and cleared at the first forward, on B's own
+    stream) must be ready whatever stream asks -- two wide networks created and stepped at once give the same match as a second
+    run on warm workspaces.  (b) `eval_cache` is ignored by a match engine: two networks alternate in a game slot and the cache
+    key carries no network id, so the switch must neither serve hits nor change a game."""
+    from matrix0_amd import arena, engine as eng
+    from matrix0_amd.backend import M0Backend
+    wide = dict(NET, channels=320, blocks=2, attention_heads=20, policy_factor_rank=128)
+
+    def match(a, b, cache):
+        c = arena.arena_cfg_from_dict(CFG, games=4, num_sims=24, max_moves=8, temp=1.0, temp_plies=4, concurrent_games=4,
+                                      leaves_per_step=8, seed=9)
+        c.eval_cache = 1 if cache else 0
+        e = eng.ArenaEngine(a, b, c)
+        recs = {}
+        while e.running():
+            e.step(8)
+            while (r := e.poll()) is not None:
+                recs[r["game_index"]] = (r["played"], float(r["result"]))
+        st = e.stats()
+        e.close()
+        return recs, st
+
+    a = M0Backend.from_state_dict(wide, net_ref.random_state_dict(wide, seed=1))
+    b = M0Backend.from_state_dict(wide, net_ref.random_state_dict(wide, seed=2))
+    cold, st_cold = match(a, b, False)            # first forwards of both networks: workspaces allocated inside the first step
+    warm, st_warm = match(a, b, False)
+    cached, st_c = match(a, b, True)
+    a.close(); b.close()
+    assert sorted(cold) == [0, 1, 2, 3]
+    assert cold == warm and st_cold["evals"] == st_warm["evals"]
+    assert cached == warm and st_c["evals"] == st_warm["evals"] and st_c["evals_cached"] == 0

@@ -71,3 +71,41 @@ def test_cache_is_off_where_the_payload_cannot_serve_the_expansion():
         e.step(8)
     assert e.stats()["evals_cached"] == 0
     e.close(); be.close()
+
+
+def test_full_size_worker_configuration_is_identical_with_and_without_the_cache():
+    """The configuration the drop-in worker and bench.py ship with: R24-320, 256 concurrent games, 800 simulations per move at
+    96 leaves per tree and pass, virtual loss on, subtree reuse -- two searched plies per game, cache on against off: the same
+    moves, the same visit distributions, and every evaluation accounted for."""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    net = dict(NET, blocks=24)
+    be = M0Backend.from_state_dict(net, net_ref.random_state_dict(net, seed=12))
+    cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in CFG.items()}
+    cfgd["mcts"] = dict(cfgd["mcts"], inference_batch_size=96, playout_random_frac=0.0)
+    cfgd["selfplay"] = dict(cfgd["selfplay"], num_simulations=800, max_game_len=2, opening_random_plies=0)
+
+    def play(cache):
+        e = eng.SelfplayEngine(be, eng.selfplay_cfg_from_dict(cfgd, concurrent_games=256, total_games=256, eval_cache=cache))
+        games = {}
+        for _ in range(400):
+            e.step(1)
+            while (r := e.poll()) is not None:
+                games[r["game_index"]] = r
+            if not e.running():
+                break
+        st = e.stats()
+        e.close()
+        return games, st
+
+    off, st_off = play(False)
+    on, st_on = play(True)
+    be.close()
+    assert sorted(off) == sorted(on) == list(range(256))
+    for i in range(256):
+        assert off[i]["played"] == on[i]["played"], i
+        for k in ("pi", "z", "s", "legal_mask", "search_values"):
+            assert np.array_equal(off[i][k], on[i][k]), (i, k)
+    assert st_on["sims"] == st_off["sims"] and st_on["plies"] == st_off["plies"] == 512
+    assert st_on["evals"] + st_on["evals_cached"] == st_off["evals"] and st_on["evals_cached"] > 0
+    print(f"eval cache [R24-320, 256 x 800 x 2 plies]: {int(st_on['evals_cached'])} of {int(st_off['evals'])} served from the cache")
