@@ -55,7 +55,24 @@ m0_net* m0_net_create(const m0_net_cfg* cfg, int hip_device) {
     if (hipSetDevice(hip_device) != hipSuccess) { m0_set_error("hipSetDevice failed"); return nullptr; }
     m0_net* h = new m0_net();
     h->device = hip_device;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    // M0_NET_CU_MASK=w0,w1,...,w7 (hex words, bit b = CU b in the driver's numbering): the network's stream runs on those CUs
+    // only (hipExtStreamCreateWithCUMask).  Measurement switch of tools/exp_cumask.py (two networks on complementary halves
+    // of the chip); read at creation, so two networks of one process can get different masks.
+    hipError_t se;
+    if (const char* mk = getenv("M0_NET_CU_MASK"); mk && *mk) {
+        uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nw = 0;
+        for (const char* q = mk; *q && nw < 8; ++nw) {
+            char* end = nullptr;
+            words[nw] = (uint32_t)strtoul(q, &end, 16);
+            if (end == q) break;
+            q = (*end == ',') ? end + 1 : end;
+        }
+        se = hipExtStreamCreateWithCUMask(&h->stream, 8, words);
+    } else {
+        se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
         m0_set_error("hipStreamCreate failed");
         delete h;
         return nullptr;

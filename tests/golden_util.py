@@ -24,3 +24,16 @@ def load_net_golden(name):
 
 
 NET_CASES = ["gn_silu_preact", "gn_dense_leaky", "bn_relu_postact", "stride2"]
+
+SEEDED_NET_CASES = ["r320x7_seeded"]
+
+
+def load_seeded_net_golden(name):
+    """Full-width fixtures (tools/gen_golden_net.py::SEEDED_CASES): cfg, seed, x and the outputs of the REFERENCE module with the
+    weights `matrix0_amd.weights.random_state_dict(cfg, seed, varied=True)` loaded into it; the weights are rebuilt here."""
+    from matrix0_amd.weights import random_state_dict
+    z = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    cfg = json.loads(str(z["cfg_json"]))
+    sd = random_state_dict(cfg, seed=int(z["seed"]), varied=True)
+    ssl = {k[4:]: z[k] for k in z.files if k.startswith("ssl_")}
+    return cfg, sd, z["x"], z["p"], z["v"], ssl

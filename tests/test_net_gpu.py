@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import net_ref
-from tests.golden_util import load_net_golden
+from tests.golden_util import SEEDED_NET_CASES, load_net_golden, load_seeded_net_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,22 @@ def test_hip_net_matches_reference_golden(name):
     assert p.shape == p_ref.shape and v.shape == v_ref.shape
     _check(f"golden:{name}", p, v, p_ref, v_ref, ssl, ssl_ref)
     assert be.param_count() == sum(int(np.prod(t.shape)) for t in sd.values())
+
+
+@pytest.mark.parametrize("name", SEEDED_NET_CASES)
+def test_hip_320_wide_kernels_match_the_reference_module(name):
+    """The kernels that are > 90 % of the GPU time (conv_zs_kernel with the GroupNorm epilogue and the fused block tail, the fused
+    attention block with and without the next block's pre-activated output, the big-tile 1x1 convs) against numbers the
+    REFERENCE module itself computed at C = 320, H = 20 (resnet.py:27-84, 137-190, 656-760) -- not through the oracle."""
+    from matrix0_amd.backend import M0Backend
+    cfg, sd, x, p_ref, v_ref, ssl_ref = load_seeded_net_golden(name)
+    be = M0Backend.from_state_dict(cfg, sd)
+    p, v, ssl = be.infer_np_ssl(x)
+    _check(f"golden:{name}", p, v, p_ref, v_ref, ssl, ssl_ref)
+    # a batch that is not a multiple of the 4-board tile / the 2-board attention workgroup
+    p3, v3 = be.infer_np(x[:3])
+    assert np.array_equal(p3, p[:3]) and np.array_equal(v3, v[:3])
+    be.close()
 
 
 def test_unsupported_config_fails_loudly():

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import net_ref
-from tests.golden_util import NET_CASES, load_net_golden
+from tests.golden_util import NET_CASES, SEEDED_NET_CASES, load_net_golden, load_seeded_net_golden
 
 
 @pytest.mark.parametrize("name", NET_CASES)
@@ -16,6 +16,19 @@ def test_oracle_matches_reference_golden(name):
     assert p.shape == (x.shape[0], 4672) and v.shape == (x.shape[0],)
     assert np.abs(p.numpy() - p_ref).max() <= 1e-4
     assert np.abs(v.numpy() - v_ref).max() <= 1e-5
+    for t, ref in ssl_ref.items():
+        assert np.abs(ssl[t].numpy() - ref).max() <= 1e-4, t
+
+
+@pytest.mark.parametrize("name", SEEDED_NET_CASES)
+def test_oracle_matches_reference_module_at_full_width(name):
+    """320 channels, 20 heads, GroupNorm(20 groups), factorised policy head, five SSL heads: the reference module's own numbers
+    (seeded weights, tools/gen_golden_net.py seeded) -- the oracle is pinned at the width the benchmark runs, not only at 32 / 64."""
+    cfg, sd, x, p_ref, v_ref, ssl_ref = load_seeded_net_golden(name)
+    p, v, ssl = net_ref.forward(sd, cfg, torch.from_numpy(x), return_ssl=True)
+    assert np.abs(p.numpy() - p_ref).max() <= 1e-4
+    assert np.abs(v.numpy() - v_ref).max() <= 1e-5
+    assert set(ssl_ref) == {"piece", "threat", "pin", "fork", "control"}
     for t, ref in ssl_ref.items():
         assert np.abs(ssl[t].numpy() - ref).max() <= 1e-4, t
 

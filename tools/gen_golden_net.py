@@ -55,9 +55,57 @@ CASES = {
 }
 
 
+# Full-width cases: the weights are NOT stored.  They are `matrix0_amd.weights.random_state_dict(cfg, seed, varied=True)` (a
+# deterministic function of cfg and seed) loaded into the reference's own PolicyValueNet; the fixture holds cfg, seed, x and what
+# the reference module computed.  These pin the 320-channel kernels (conv_zs_kernel with every epilogue, attn_block_kernel,
+# the big-tile 1x1 convs) to the reference module itself rather than through the oracle.
+SEEDED_CASES = {
+    # blocks=7, attention_every_k=3: res, res, res+ATTENTION, res, res, res+ATTENTION, res -- one attention block followed by a
+    # residual block (the fused block writes the next block's pre-activated input too) and ... the same again, then the heads
+    "r320x7_seeded": (dict(planes=19, channels=320, blocks=7, attention_heads=20, policy_size=4672, norm="group",
+                           activation="silu", preact=True, policy_factor_rank=128, self_supervised=True,
+                           ssl_tasks=["piece", "threat", "pin", "fork", "control"]), 21, 8),
+}
+
+
+def gen_seeded(mod):
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from matrix0_amd.weights import random_state_dict
+    for name, (cfg, seed, B) in SEEDED_CASES.items():
+        torch.manual_seed(1234)
+        net = mod.PolicyValueNet(mod.NetConfig(**cfg)).eval()
+        sd = random_state_dict(cfg, seed=seed, varied=True)
+        res = net.load_state_dict(sd, strict=False)
+        # the only keys of the module the generator does not produce are the aliases of ssl_heads.piece.* (resnet.py:436-437)
+        missing = [k for k in res.missing_keys if not (k.startswith("ssl_head.") or k.startswith("ssl_piece_head."))]
+        assert not missing and not res.unexpected_keys, (missing, res.unexpected_keys)
+        own = dict(net.state_dict())
+        for k, t in sd.items():
+            assert torch.equal(own[k], t.reshape(own[k].shape).to(own[k].dtype)), k
+        g = torch.Generator().manual_seed(1000 + seed)
+        x = torch.zeros(B, 19, 8, 8)
+        x[:, :12] = (torch.rand(B, 12, 8, 8, generator=g) < 0.08).float()
+        x[:, 12:17] = (torch.rand(B, 5, 1, 1, generator=g) < 0.5).float()
+        x[:, 17:] = torch.rand(B, 2, 1, 1, generator=g)
+        with torch.no_grad():
+            p, v, ssl = net(x, return_ssl=True)
+        blob = {"cfg_json": np.array(json.dumps(cfg)), "seed": np.array(seed), "x": x.numpy(), "p": p.numpy(), "v": v.numpy()}
+        for t, arr in ssl.items():
+            blob[f"ssl_{t}"] = arr.numpy()
+        path = os.path.join(OUT, f"net_{name}.npz")
+        np.savez_compressed(path, **blob)
+        print(name, "params", sum(int(t.numel()) for t in sd.values()), "p", tuple(p.shape), "|p|max", float(p.abs().max()),
+              "v", v.numpy().round(4), os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     mod = load_reference_resnet()
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "seeded":
+        gen_seeded(mod)
+        return
     for name, (cfg, B) in CASES.items():
         torch.manual_seed(1234)
         net = mod.PolicyValueNet(mod.NetConfig(**cfg)).eval()
@@ -116,6 +164,9 @@ def main():
         np.savez_compressed(path, **blob)
         print(name, "params", sum(int(np.prod(blob['sd::' + k].shape)) for k in seen if 'sd::'+k in blob),
               "p", p.shape, "v", v.numpy(), os.path.getsize(path) // 1024, "KiB")
+
+
+    gen_seeded(mod)
 
 
 if __name__ == "__main__":
