@@ -199,6 +199,8 @@ def main():
                     help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
                          "+3..4 %% games/s, but per-launch kernel timings then include the other stream's kernels, so the "
                          "roofline of the default run is taken with 1")
+    ap.add_argument("--cu-split", action="store_true",
+                    help="experiment (with --streams 2): the two engines' streams run on complementary CU halves of every XCD")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,7 +236,19 @@ def main():
     sd = random_state_dict(R24_320, seed=0, varied=True) if rank == 0 else None
     if distributed:
         sd = m0dist.broadcast_state_dict(sd, R24_320, src=0, device=torch.device("cuda", local_rank))
-    be = M0Backend.from_state_dict(R24_320, sd, device_index=local_rank)
+    # --cu-split (experiment, with --streams 2): the two engines' streams get complementary halves of the CUs of every XCD
+    # (hipExtStreamCreateWithCUMask through M0_NET_CU_MASK, read when a network is created)
+    cu_masks = ["ffffffff,ffffffff,ffffffff,ffffffff,0,0,0,0", "0,0,0,0,ffffffff,ffffffff,ffffffff,ffffffff"] if args.cu_split else []
+
+    def make_backend():
+        if cu_masks:
+            os.environ["M0_NET_CU_MASK"] = cu_masks.pop(0)
+        try:
+            return M0Backend.from_state_dict(R24_320, sd, device_index=local_rank)
+        finally:
+            os.environ.pop("M0_NET_CU_MASK", None)
+
+    be = make_backend()
     flops_eval = be.flops_per_position(with_ssl=args.ssl)
 
     cfg_dict = json.loads(json.dumps(SELFPLAY_CFG))
@@ -256,7 +270,7 @@ def main():
                   virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache)
         if args.streams > 1:
             made = [be]
-            e = eng.SelfplayPool(lambda: made.pop() if made else M0Backend.from_state_dict(R24_320, sd, device_index=local_rank),
+            e = eng.SelfplayPool(lambda: made.pop() if made else make_backend(),
                                  cfg_dict, streams=args.streams, **kw)
         else:
             e = eng.SelfplayEngine(be, eng.selfplay_cfg_from_dict(cfg_dict, **kw))

@@ -198,8 +198,9 @@ int m0_net_bench_forward(m0_net* n, int B, int iters, int with_ssl, float* ms_pe
     int rc = ensure_io(n, B);
     if (rc != M0_OK) return rc;
     std::string err;
-    // synthetic resident input: sparse 0/1 piece planes + constant planes
-    {
+    // synthetic resident input: sparse 0/1 piece planes + constant planes (with_ssl bit 1: keep the input of the previous call
+    // of the same batch size -- tools/exp_cumask.py times two networks side by side without the host-side generation)
+    if (!(with_ssl & 2)) {
         const int P = n->net->cfg().planes;
         std::vector<float> h((size_t)B * P * 64, 0.f);
         uint64_t s = 0x9E3779B97F4A7C15ull;
@@ -211,7 +212,7 @@ int m0_net_bench_forward(m0_net* n, int B, int iters, int with_ssl, float* ms_pe
         }
         (void)hipMemcpy(n->planes_dev, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     }
-    float* ssl = (with_ssl && n->net->ssl_channels_total() > 0) ? n->ssl_dev : nullptr;
+    float* ssl = ((with_ssl & 1) && n->net->ssl_channels_total() > 0) ? n->ssl_dev : nullptr;
     rc = n->net->forward(n->planes_dev, nullptr, B, n->logits_dev, n->value_dev, ssl, n->stream, err);   // warm-up
     if (rc != M0_OK) { m0_set_error(err); return rc; }
     hipEvent_t e0, e1;

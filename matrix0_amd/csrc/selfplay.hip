@@ -411,18 +411,26 @@ int apply_advances(m0_selfplay* sp, std::vector<int>& ids, std::vector<int>& slo
 
 int step_back(m0_selfplay* sp, int rows, double t0, std::string& err);
 
-// Several engines on one GPU (engine.SelfplayPool): their network forwards take turns.  A forward fills the chip, so two in
-// flight only time-slice each other; what the second engine adds is that its tree kernels and host work run while the other
-// engine's forward owns the chip.  The gate is held from the first launch of a forward until its last kernel has finished.
+// Several engines on one GPU (engine.SelfplayPool).  By default their forwards simply overlap on the chip.  With
+// M0_FORWARD_GATE=1 (read once) the forwards of engines that own a network on the same device take turns instead: what the
+// second engine then adds is that its tree kernels and host work run while the other engine's forward owns the chip, and a
+// conv launch's event-bracketed time stays a measurement of that kernel alone.  Measured: gated 1.098
+// against 1.121 games/s with one engine in round 3 -- the gate is a measurement aid, not a speed-up, hence opt-in.  It is held
+// from the first launch of a forward until its last kernel has finished and is skipped by a step without rows.
 constexpr int M0_MAX_DEVICES = 16;
 std::mutex g_forward_gate[M0_MAX_DEVICES];
 std::atomic<int> g_engines_with_net[M0_MAX_DEVICES];
+bool forward_gate_enabled() {
+    static const bool on = [] { const char* v = getenv("M0_FORWARD_GATE"); return v && v[0] == '1'; }();
+    return on;
+}
 
 struct ForwardGate {
     std::mutex* m = nullptr;
     hipStream_t st = nullptr;
-    ForwardGate(int device, hipStream_t stream) : st(stream) {
-        if ((unsigned)device < (unsigned)M0_MAX_DEVICES && g_engines_with_net[device].load(std::memory_order_relaxed) > 1) {
+    ForwardGate(int device, hipStream_t stream, bool has_rows) : st(stream) {
+        if (has_rows && forward_gate_enabled() && (unsigned)device < (unsigned)M0_MAX_DEVICES &&
+            g_engines_with_net[device].load(std::memory_order_relaxed) > 1) {
             m = &g_forward_gate[device];
             m->lock();
         }
@@ -440,7 +448,7 @@ int one_step(m0_selfplay* sp, std::string& err) {
     if (run_select(sp, &rows) != 0) { err = std::string("select failed: ") + hipGetErrorString(hipGetLastError()); return M0_ERR_HIP; }
     (void)hipEventRecord(sp->ev1, sp->stream);
     if (rows > sp->rows_max || sp->rows2[1] > sp->rows_max) { err = "row counter overflow"; return M0_ERR_STATE; }
-    ForwardGate gate(sp->device, sp->stream);
+    ForwardGate gate(sp->device, sp->stream, rows > 0 || sp->rows2[1] > 0);
     if (rows > 0) {
         if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
         m0_net_lock(sp->nethandle);          // an infer_np on the same backend from another thread waits here

@@ -34,7 +34,8 @@ _W_NOSTM[12 * 64:13 * 64] = 0
 
 
 class HashNet:
-    def __init__(self, seed=0, sharp=8.0, vscale=0.9, vbias=0.0, stm_oriented=True, poison=False):
+    def __init__(self, seed=0, sharp=8.0, vscale=0.9, vbias=0.0, stm_oriented=True, poison=False, boost_white=None,
+                 boost_black=None):
         self.seed = np.uint64(seed)
         self.sharp = np.float32(sharp)
         self.vscale = np.float32(vscale)
@@ -42,6 +43,7 @@ class HashNet:
         self.stm_oriented = stm_oriented
         self.poison = poison          # some positions get one non-finite logit (Node._expand's uniform fallback)
         self.calls = 0
+        self.boost = [[(int(i), np.float32(b)) for i, b in (bb or [])] for bb in (boost_black, boost_white)]   # [black, white]
 
     def infer_np(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -62,6 +64,12 @@ class HashNet:
             value = np.where(white, base, -base).astype(np.float32)
         else:
             value = base.astype(np.float32)
+        if self.boost[0] or self.boost[1]:
+            wtm = x[:, 12, 0, 0] > 0.5
+            for side in (0, 1):
+                rows = np.nonzero(wtm == bool(side))[0]
+                for i, b in self.boost[side]:
+                    logits[rows, i] = logits[rows, i] + b
         if self.poison:
             sel = (h % np.uint64(5)).astype(np.int64)
             for i in range(B):

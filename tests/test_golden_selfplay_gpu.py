@@ -121,6 +121,10 @@ def test_match_engine_plays_the_reference_arena_game(gi):
             pi[i] = np.float32(n / tot)
         assert np.array_equal(rec["pi"][t], pi), f"visit counts at ply {t} (side {want['side']})"
         assert abs(float(rec["search_values"][t]) - want["root_q"]) < 1e-6, t
-    # unfinished / adjudicated games are 1/2-1/2 (arena.py:121-123): result 0 from White's point of view
-    assert g["result"] == "1/2-1/2" and rec["result"] == 0.0
+    # arena.py:112-126: a finished game is scored by board.result(claim_draw=True), an unfinished / adjudicated one is 1/2-1/2;
+    # the engine reports the result from White's point of view (+1 / 0 / -1) -- three of the goldens end in mate
+    assert rec["result"] == {"1-0": 1.0, "0-1": -1.0, "1/2-1/2": 0.0}[g["result"]]
+    from matrix0_amd import arena as m0arena
+    res_str = m0arena.result_string(float(rec["result"]), True)
+    assert res_str == g["result"] and m0arena.game_score(res_str, g["uid"] % 2 == 0) == g["score"]
     assert (na.calls, nb.calls) == (g["evals_a"], g["evals_b"])

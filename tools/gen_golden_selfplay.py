@@ -345,6 +345,44 @@ ARENA_CASES = [
 ]
 
 
+def _script_boosts(line, bonus0=45.0, step=6.0):
+    """Rigged evaluators for a scripted game from the start position (the reference's arena always starts there, arena.py:63):
+    the policy index of every scripted move with a bonus that falls along the line, per colour -- where an earlier scripted
+    move is still legal it outranks the later ones, and a move that is no longer legal is masked by the legal softmax."""
+    b = ch.Board()
+    out = {True: [], False: []}
+    for k, u in enumerate(line):
+        m = ch.Move.from_uci(u)
+        out[bool(b.turn)].append([int(ch.move_to_index(b, m)), float(bonus0 - step * (k // 2))])
+        b.push(m)
+    assert b.is_checkmate(), line
+    return out[True], out[False]
+
+
+def _decisive_cases():
+    """Three games that END IN MATE inside the move cap (arena.py:112-120, the decisive branch): every search is prior-driven (few
+    simulations, flat values, no Dirichlet noise -- as arena.py:365-381 sets evaluation searches up), each side's own evaluator
+    is rigged along the script.  Note what running the reference shows here: `_select` scores a child by child.q, which
+    `_backpropagate` keeps from the CHILD's side to move (mcts.py:866-881, 946-953), so a mating move's child has q = -1 and the
+    search steers AWAY from it; with a prior of ~1 it still collects the most visits (c sqrt(N) / (1 + n) > 1 up to n ~ 13 of
+    24) and is played by the most-visited rule."""
+    scholar = ["e2e4", "e7e5", "d1h5", "b8c6", "f1c4", "g8f6", "h5f7"]          # 4. Qxf7#: White mates
+    fool = ["f2f3", "e7e5", "g2g4", "d8h4"]                                     # 2... Qh4#: Black mates
+    sw, sb = _script_boosts(scholar)
+    fw, fb = _script_boosts(fool)
+    return [
+        # A is White and mates: 1-0, score 1
+        (4, {"seed": 61, "sharp": 2.0, "vscale": 0.05, "boost_white": sw, "boost_black": sb},
+            {"seed": 62, "sharp": 2.0, "vscale": 0.05, "boost_black": sb}, 24, 8, 40, 0.0, 0, {"selection_jitter": 0.0, "dirichlet_frac": 0.0}, {}),
+        # B is White and mates: 1-0, score 0
+        (5, {"seed": 63, "sharp": 2.0, "vscale": 0.05, "boost_black": sb},
+            {"seed": 64, "sharp": 2.0, "vscale": 0.05, "boost_white": sw, "boost_black": sb}, 24, 8, 40, 0.0, 0, {"selection_jitter": 0.0, "dirichlet_frac": 0.0}, {}),
+        # A is White and is mated by B: 0-1, score 0 (sampled moves: the rigged prior leaves the sampler nothing to choose)
+        (6, {"seed": 65, "sharp": 2.0, "vscale": 0.05, "boost_white": fw},
+            {"seed": 66, "sharp": 2.0, "vscale": 0.05, "boost_white": fw, "boost_black": fb}, 32, 16, 40, 0.3, 4, {"dirichlet_frac": 0.0}, {}),
+    ]
+
+
 def gen_arena():
     """ref_arena.json.gz: whole games of the reference's own _arena_run_one_game (arena.py:59-126) with REAL searches: two MCTS
     objects (one per side, kept across the moves as arena.py:157-158 does) behind two different evaluators.  tt = "off": the
@@ -355,7 +393,7 @@ def gen_arena():
     from azchess.config import Config as RConfig
     games = []
     for tt in ("off", "on"):
-      for (gi, net_a, net_b, sims, L, max_moves, temp, temp_plies, mextra, draw) in ARENA_CASES:
+      for (gi, net_a, net_b, sims, L, max_moves, temp, temp_plies, mextra, draw) in ARENA_CASES + _decisive_cases():
           mcfg = dict(BASE_MCTS, inference_batch_size=L, num_simulations=sims, **mextra)
           na, nb = HashNet(**net_a), HashNet(**net_b)
           A = rmcts.MCTS(rmcts.MCTSConfig.from_dict(dict(mcfg)), None, device="cpu", inference_backend=na)
@@ -402,6 +440,8 @@ def gen_arena():
                         "trace": trace, "chosen": chosen, "final_fen": b.fen(), "evals_a": na.calls, "evals_b": nb.calls,
                         "draws": {"jitter": st.jitter.ctr, "noise": st.noise.ctr, "dirichlet": st.dirichlet.ctr, "game": st.game.ctr}})
           print(f"arena game {gi} tt={tt}: plies={nmoves} result={res} score_A={score} evals A/B = {na.calls}/{nb.calls}", flush=True)
+          if gi >= 4:
+              assert res == {4: "1-0", 5: "1-0", 6: "0-1"}[gi] and score == {4: 1.0, 5: 0.0, 6: 0.0}[gi], (gi, res, score)
     dump_json("ref_arena.json.gz", {"seed": 8080, "games": games})
 
 
