@@ -127,7 +127,10 @@ def play_match(backend_a, backend_b, games: int, cfg: dict, seed: Optional[int] 
         # per-side tables for the whole game: nothing is compacted, so a side's arena half must hold every node it creates in the
         # game (~40 per simulation and search).  Size it, and keep the resident games within ~96 GB of node storage.
         nodes = int(min(8_000_000, max(65536, num_sims * 40 * (max_moves // 2 + 2))))
-        per_game = 2 * nodes * 46 + 2 * 2 * nodes * 12                 # two halves of SoA nodes + two tables (keys + node ids, 2x)
+        tcap = 1024
+        while tcap < 2 * nodes:                                        # selfplay_create_impl rounds a table up to a power of two
+            tcap <<= 1
+        per_game = 2 * nodes * 46 + 2 * tcap * 12                      # two halves of SoA nodes + two tables (8-byte key + 4-byte node)
         conc = max(1, min(conc, int(96e9 // per_game)))
         cfg = dict(cfg, engine=dict(ecfg, arena_nodes=nodes))
     c = arena_cfg_from_dict(cfg, games=games, num_sims=num_sims, max_moves=max_moves, temp=temp, temp_plies=temp_plies,

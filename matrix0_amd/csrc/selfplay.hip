@@ -621,6 +621,9 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
         sp->d.tt_cap = tc;
         // match engine: one table per side, kept for the whole game (the reference keeps one MCTS object per side, arena.py:157-158)
         sp->d.tt_sides = sp->cfg.arena_mode ? 2 : 1;
+        // a side's half that cannot hold one more search starts over BEFORE that search (advance_kernel), not in the middle of it:
+        // ~35 children per expansion on average, 48 with margin, never more than half of the half
+        sp->d.search_nodes = (int)std::min<long>((long)cfg->num_simulations * 48 + 4 * M0_MAX_CHILDREN, (long)sp->cap / 2);
         sp->d.epaths = dalloc<int>(sp, (size_t)sp->G * LS * M0_MAX_DEPTH);
         sp->d.tt_keys = dalloc<uint64_t>(sp, (size_t)sp->G * sp->d.tt_sides * tc);
         sp->d.tt_nodes = dalloc<int>(sp, (size_t)sp->G * sp->d.tt_sides * tc);

@@ -131,6 +131,8 @@ struct TreeDev {
     int* tt_nodes;            // tt_merge: [G][tt_cap] node registered LAST under the key
     int tt_cap;               // entries per table, a power of two
     EvalCache ec;
+    int search_nodes;         // head-room a per-side half (tt_sides == 2) must have before a search starts there: the nodes one
+                              // search can create (~48 per simulation incl. margin); with less the half starts over first
     int tt_sides;             // tables per game: 1, or 2 in a match engine with compat.tt_merge (one per side, kept all game:
                               // the reference keeps one MCTS object, hence one table, per side -- arena.py:157-158)
     uint16_t* leaf_moves;     // [G][L+1][M0_MAX_CHILDREN] legal moves of each sampled leaf, generation order

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_
         int node = slot == -3 ? -1 : tt_lookup(TK, TN, d.tt_cap, tt_key_of(gd->root_pos), lane);
         // a half that cannot take another search's worth of nodes starts over: its table is dropped and the search begins from a
         // fresh root (what the reference's _cleanup_memory does to an over-full table); engine.arena_nodes sizes it for a game
-        if (nxt + 4 * M0_MAX_CHILDREN >= d.t.cap) {
+        if (nxt + (d.search_nodes > 4 * M0_MAX_CHILDREN ? d.search_nodes : 4 * M0_MAX_CHILDREN) >= d.t.cap) {
             uint4* tk = reinterpret_cast<uint4*>(d.tt_keys + ((size_t)g * 2 + s) * d.tt_cap);
             for (int i = lane; i < d.tt_cap / 2; i += 64) tk[i] = make_uint4(0, 0, 0, 0);
             nxt = 0; node = -1;

@@ -6,7 +6,11 @@ random.choice(OPENING_BOOK).
 Here the movetext is parsed directly: every SAN token is matched against the SAN of the legal moves of the current position
 (m0_san_legal_fen: python-chess Board.san() semantics, pinned by the 7 875 SAN tokens of the reference's own PGN files,
 tests/test_san_pgn.py), the position is advanced with m0_fen_after, and the book is handed to the engine as FEN strings
-(m0_selfplay_set_openings), which picks with the game's own stream as random.choice would.  Host code, no GPU."""
+(m0_selfplay_set_openings), which picks with the game's own stream as random.choice would.  Host code, no GPU.
+
+Known deviation: the reference stores board.copy() WITH its move stack, so the book line's moves count towards repetition /
+claim_draw in the game that starts there; a FEN carries no history, so a game started from the book begins with an empty
+repetition window (a repetition that needs pre-book positions is seen 1-2 occurrences later than the reference would)."""
 from __future__ import annotations
 
 import re
@@ -25,7 +29,12 @@ def _norm(tok: str) -> str:
     tok = tok.rstrip("!?")
     if tok.startswith(("0-0-0", "0-0")):
         tok = tok.replace("0", "O")
-    return tok.rstrip("+#")
+    tok = tok.rstrip("+#")
+    # python-chess's SAN reader also takes a promotion written without '=' ("e8Q", "dxe8N")
+    m = re.fullmatch(r"(.*[a-h][18])([QRBN])", tok)
+    if m and "=" not in tok:
+        tok = m.group(1) + "=" + m.group(2)
+    return tok
 
 
 def _games(text: str):
@@ -49,7 +58,8 @@ def _games(text: str):
 def mainline_fens(headers: dict, movetext: str, max_plies: int) -> List[str]:
     """FEN after each of the first `max_plies` mainline moves (variations, comments, NAGs and move numbers skipped; parsing of a
     game stops at its first token that is not the SAN of a legal move, as python-chess records an error and ends the line)."""
-    fen = headers.get("FEN") if headers.get("SetUp", "1") == "1" and headers.get("FEN") else START_FEN
+    # python-chess's Game.board() starts from the FEN header whenever there is one (SetUp is not consulted)
+    fen = headers.get("FEN") or START_FEN
     out: List[str] = []
     depth = 0
     for tok in _TOKEN.findall(movetext):

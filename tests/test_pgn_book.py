@@ -90,6 +90,11 @@ def test_setup_fen_header_and_bad_token():
     heads = {"SetUp": "1", "FEN": fen}
     got = pgn_book.mainline_fens(heads, "1. e4 Kd7 2. e5 Kc6 Zz9 3. e6", 20)
     assert got == _oracle_fens(["e2e4", "e8d7", "e4e5", "d7c6"], start=fen)       # stops at the unreadable token
+    # the FEN header is honoured with or without SetUp (python-chess's Game.board()), and "e8Q" reads as "e8=Q"
+    assert pgn_book.mainline_fens({"FEN": fen}, "1. e4", 20) == _oracle_fens(["e2e4"], start=fen)
+    pfen = "8/4P1k1/8/8/8/8/8/4K3 w - - 0 1"
+    assert pgn_book.mainline_fens({"FEN": pfen}, "1. e8Q Kf6", 20) == _oracle_fens(["e7e8q", "g7f6"], start=pfen)
+    assert pgn_book.mainline_fens({"FEN": pfen}, "1. e8=N+ Kf8", 20) == _oracle_fens(["e7e8n", "g7f8"], start=pfen)
     assert pgn_book.mainline_fens({}, "1. e4 e5 2. Nf3 *  3. Nc3", 20) == _oracle_fens(["e2e4", "e7e5", "g1f3"])
     assert pgn_book.mainline_fens({}, "1. e4 e5 2. Nf3 Nc6", 3) == _oracle_fens(["e2e4", "e7e5", "g1f3"])
 
