@@ -21,8 +21,8 @@
 // pieces in consumption order (qkv(0..9), then proj k-step 0..9 x 2 halves) through a 4-slot LDS ring filled three pieces ahead
 // by global_load_lds from the G-waves (counted vmcnt: they have nothing else in flight, kernel_common.h); an A-wave's work of a
 // period is cut into 5 chunks, one per piece of that period.
-#include "kernel_common.h"
-#include "conv_epilogue.h"
+#include "../../matrix0_amd/csrc/kernel_common.h"
+#include "../../matrix0_amd/csrc/conv_epilogue.h"
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));

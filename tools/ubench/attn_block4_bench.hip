@@ -1,11 +1,11 @@
-// Stand-alone check + timing of attn_block3_kernel (round 4: 16 role-specialised waves) against a plain fp32 CPU computation of the
+// Stand-alone check + timing of attn_block4_kernel (round 4: 16 role-specialised waves) against a plain fp32 CPU computation of the
 // block (qkv and O rounded to fp16 where the kernel rounds them) and against round 3's attn_block_kernel on the same synthetic data.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ubench/attn_block3_bench.hip -o attn_block3_bench
-//   ./attn_block3_bench [boards] [iters]
-//   -DA3_DRY    barrier-count check only (the main loop's barriers become counters; all 16 waves must report the same count)
-//   -DA3_STAMP  s_memtime stamps of wave 0 (attention role) and wave 8 (GEMM role) of every workgroup
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ubench/attn_block4_bench.hip -o attn_block4_bench
+//   ./attn_block4_bench [boards] [iters]
+//   -DA4_DRY    barrier-count check only (the main loop's barriers become counters; all 16 waves must report the same count)
+//   -DA4_STAMP  s_memtime stamps of wave 0 (attention role) and wave 8 (GEMM role) of every workgroup
 #include "../../matrix0_amd/csrc/attn_block.hip"
-#include "attn_block3.hip"
+#include "attn_block4.hip"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,7 +20,7 @@ static void pack_piece(const std::vector<float>& wq, const std::vector<float>& w
             const int J = col >> 4, type = J >> 1, hl = J & 1, d = col & 15;
             for (int k = 0; k < 64; ++k) {
                 const int pos = (k >> 3) ^ ((col >> 1) & 7);
-                const int ksrc = kperm ? (k & ~31) + attn_block3_qkv_kperm(k & 31) : k;
+                const int ksrc = kperm ? (k & ~31) + attn_block4_qkv_kperm(k & 31) : k;
                 dst[(size_t)col * 64 + pos * 8 + (k & 7)] = (_Float16)wq[(size_t)((type * 20 + 2 * g + hl) * 16 + d) * Cr + 64 * pc + ksrc];
             }
         }
@@ -69,16 +69,35 @@ int main(int argc, char** argv) {
             bool vis = dr == 0 || dc == 0 || adr == adc || (adr == 2 && adc == 1) || (adr == 1 && adc == 2);
             if (vis) mask[i] |= 1ull << j;
         }
-    std::vector<_Float16> buf1(attn_block_pack_bytes() / 2, (_Float16)0.f), buf2(attn_block3_pack_bytes() / 2, (_Float16)0.f), bb;
+    std::vector<_Float16> buf1(attn_block_pack_bytes() / 2, (_Float16)0.f), buf2(attn_block4_pack_bytes() / 2, (_Float16)0.f), bb;
     for (int g = 0; g < 10; ++g)
-        for (int pc = 0; pc < 7; ++pc) {
-            pack_piece(wq, wp, g, pc, &buf1[(size_t)(g * 7 + pc) * 6144]);
-            pack_piece(wq, wp, g, pc, &buf2[(size_t)attn_block3_stream_pos(g, pc) * 6144], true);
+        for (int pc = 0; pc < 7; ++pc) pack_piece(wq, wp, g, pc, &buf1[(size_t)(g * 7 + pc) * 6144]);
+    {
+        std::vector<int> seen(80, 0);
+        for (int g = 0; g < 10; ++g) {
+            for (int j = 0; j < 6; ++j) {          // qkv tile j of group g: [16 channels][320 k], 640-byte rows, chunk ^ (row>>1)&7 in 128 B
+                _Float16* dst = &buf2[(size_t)attn_block4_qkv_pos(g, j) * 5120];
+                seen[attn_block4_qkv_pos(g, j)]++;
+                const int type = j >> 1, hl = j & 1;
+                for (int col = 0; col < 16; ++col)
+                    for (int k = 0; k < 320; ++k) {
+                        const int s = k >> 5, kl = k & 31, c = 4 * s + (kl >> 3);
+                        const int pos = (c & ~7) | ((c ^ (col >> 1)) & 7);
+                        dst[(size_t)col * 320 + pos * 8 + (kl & 7)] =
+                            (_Float16)wq[(size_t)((type * 20 + 2 * g + hl) * 16 + col) * 320 + 32 * s + attn_block4_qkv_kperm(kl)];
+                    }
+            }
+            for (int hh = 0; hh < 2; ++hh) {       // proj k-step g, channels 160 hh ..: [160][32 k], 64-byte rows
+                _Float16* dst = &buf2[(size_t)attn_block4_proj_pos(g, hh) * 5120];
+                seen[attn_block4_proj_pos(g, hh)]++;
+                for (int cl = 0; cl < 160; ++cl)
+                    for (int k = 0; k < 32; ++k) {
+                        const int pos = (k >> 3) ^ ((4 - ((cl >> 2) & 3)) & 3);
+                        dst[(size_t)cl * 32 + pos * 8 + (k & 7)] = (_Float16)wp[(size_t)(160 * hh + cl) * 320 + (2 * g + (k >> 4)) * 16 + (k & 15)];
+                    }
+            }
         }
-    {   // every stream position used exactly once
-        std::vector<int> seen(70, 0);
-        for (int g = 0; g < 10; ++g) for (int pc = 0; pc < 7; ++pc) seen[attn_block3_stream_pos(g, pc)]++;
-        for (int t = 0; t < 70; ++t) if (seen[t] != 1) { printf("stream position %d used %d times\n", t, seen[t]); return 3; }
+        for (int t = 0; t < 80; ++t) if (seen[t] != 1) { printf("stream position %d used %d times\n", t, seen[t]); return 3; }
     }
     pack_bias(rb, bb);
     _Float16 *dx, *dy, *dy2, *dyo, *dy2o, *dbb; void *dw1, *dw2; uint64_t* dm; float *dlg, *dlb, *dg2, *db2;
@@ -98,14 +117,14 @@ int main(int argc, char** argv) {
     AttnBlockArgs ao = a;
     ao.wpack = dw1; ao.y = dyo; ao.y2 = dy2o;
     hipStream_t st; hipStreamCreate(&st);
-#ifdef A3_STAMP
-    unsigned long long* dst_ab; hipMalloc(&dst_ab, (size_t)(boards / 2) * 32 * 8); hipMemset(dst_ab, 0, (size_t)(boards / 2) * 32 * 8);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_a3_stamp), &dst_ab, sizeof(dst_ab));
+#if defined(A4_STAMP) || defined(A4_STAMP2)
+    unsigned long long* dst_ab; hipMalloc(&dst_ab, (size_t)(boards / 2) * 64 * 8); hipMemset(dst_ab, 0, (size_t)(boards / 2) * 64 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_a4_stamp), &dst_ab, sizeof(dst_ab));
 #endif
-    hipError_t e = launch_attn_block3(a, st);
+    hipError_t e = launch_attn_block4(a, st);
     hipError_t e2 = hipStreamSynchronize(st);
     if (e != hipSuccess || e2 != hipSuccess) { printf("launch failed: %s / %s\n", hipGetErrorString(e), hipGetErrorString(e2)); return 1; }
-#ifdef A3_DRY
+#ifdef A4_DRY
     {
         std::vector<int> cnt((size_t)(boards / 2) * 16);
         hipMemcpy(cnt.data(), dy, cnt.size() * 4, hipMemcpyDeviceToHost);
@@ -220,10 +239,10 @@ int main(int argc, char** argv) {
         printf("output hash: y %016llx  y2 %016llx\n", (unsigned long long)hsh[0], (unsigned long long)hsh[1]);
     }
     auto time_it = [&](bool neu) {
-        for (int i = 0; i < 3; ++i) neu ? launch_attn_block3(a, st) : launch_attn_block(ao, st);
+        for (int i = 0; i < 3; ++i) neu ? launch_attn_block4(a, st) : launch_attn_block(ao, st);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, st);
-        for (int i = 0; i < iters; ++i) neu ? launch_attn_block3(a, st) : launch_attn_block(ao, st);
+        for (int i = 0; i < iters; ++i) neu ? launch_attn_block4(a, st) : launch_attn_block(ao, st);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
@@ -240,19 +259,36 @@ int main(int argc, char** argv) {
             if (h != hsh[o]) { printf("NOT DETERMINISTIC: output %d hash %016llx after the timed launches\n", o, (unsigned long long)h); ++nbad; }
         }
     }
-#ifdef A3_STAMP
+#ifdef A4_STAMP2
+    {   // per wave 0 / 4 (attention) and 8 / 12 (GEMM): work time between barriers and wait time at them, intervals 18-23
+        const int nb2 = boards / 2;
+        std::vector<unsigned long long> hs((size_t)nb2 * 64);
+        hipMemcpy(hs.data(), dst_ab, hs.size() * 8, hipMemcpyDeviceToHost);
+        for (int wv = 0; wv < 4; ++wv) {
+            printf(" wave %2d (%s):", 4 * wv, wv < 2 ? "attention" : "GEMM");
+            for (int k = 0; k < 11; ++k) {
+                std::vector<double> d;
+                for (int b = 0; b < nb2; ++b) d.push_back((double)(hs[((size_t)b * 4 + wv) * 16 + k + 1] - hs[((size_t)b * 4 + wv) * 16 + k]));
+                std::sort(d.begin(), d.end());
+                printf(" %s%5.0f", (k & 1) ? "work " : "wait ", d[d.size() / 2]);
+            }
+            printf("\n");
+        }
+    }
+#endif
+#ifdef A4_STAMP
     {
         const int nb2 = boards / 2;
         std::vector<unsigned long long> hs((size_t)nb2 * 32);
         hipMemcpy(hs.data(), dst_ab, hs.size() * 8, hipMemcpyDeviceToHost);
-        const char* namesA[] = {"prologue + qkv(0) (5 pieces)", "periods 0-4 (25 pieces)", "period 5 (5 pieces)", "periods 6-8 (15 pieces)", "period 9 = proj pieces 0-4",
-                                "proj pieces 5-19", "(final barrier)", "", ""};
-        const char* namesG[] = {"prologue + qkv(0) (5 pieces)", "periods 0-4 (25 pieces)", "period 5 (5 pieces)", "periods 6-8 (15 pieces)", "proj (20 pieces)",
-                                "final barrier", "LayerNorm + flush y", "GroupNorm + y2", ""};
+        const char* namesA[] = {"prologue + qkv(0) (3 intervals)", "periods 0-4 (15 intervals)", "period 5 (3 intervals)", "periods 6-8 (9 intervals)",
+                                "period 9 (3 intervals, beside proj)", "proj (7 intervals)", "final barrier", "", ""};
+        const char* namesG[] = {"prologue + qkv(0) (3 intervals)", "periods 0-4 (15 intervals)", "period 5 (3 intervals)", "periods 6-8 (9 intervals)",
+                                "proj (10 intervals)", "final barrier", "LayerNorm + flush y", "GroupNorm + y2", ""};
         for (int role = 0; role < 2; ++role) {
             printf(" %s wave:\n", role ? "GEMM" : "attention");
             const char** names = role ? namesG : namesA;
-            for (int k = 0; k < (role ? 8 : 6); ++k) {
+            for (int k = 0; k < (role ? 8 : 7); ++k) {
                 std::vector<double> d;
                 for (int b = 0; b < nb2; ++b) d.push_back((double)(hs[((size_t)b * 2 + role) * 16 + k + 1] - hs[((size_t)b * 2 + role) * 16 + k]));
                 std::sort(d.begin(), d.end());
@@ -262,6 +298,6 @@ int main(int argc, char** argv) {
     }
 #endif
     printf("attn_block  (round 3) boards %d: %.1f / %.1f us per launch, %.3f PFLOP/s\n", boards, us_old, us_old2, flop / us_old2 * 1e-9);
-    printf("attn_block3 (round 4) boards %d: %.1f / %.1f us per launch, %.3f PFLOP/s\n", boards, us_new, us_new2, flop / us_new2 * 1e-9);
+    printf("attn_block4 (round 4) boards %d: %.1f / %.1f us per launch, %.3f PFLOP/s\n", boards, us_new, us_new2, flop / us_new2 * 1e-9);
     return nbad ? 2 : 0;
 }
