@@ -95,7 +95,7 @@ private:
     m0_net_cfg cfg_;
     int device_;
     hipStream_t stream_ = nullptr;
-    struct Switches { bool fuse_tail = true, fuse_attn = true, splitk = true, conv_zs = true; } sw_;   // read once (constructor)
+    struct Switches { bool fuse_tail = true, fuse_attn = true, splitk = true, conv_zs = true, fuse_small = true; } sw_;   // read once (constructor)
     bool finalized_ = false;
     size_t nparams_ = 0;
     std::map<std::string, HostTensor> sd_;
@@ -113,6 +113,8 @@ private:
     std::vector<AttnW> att_;
     std::vector<TowerLayer> tower_;
     PackedGemm ph_conv_, pfc1_, pfc2_;
+    PackedGemm hv_;          // policy_head.0 and value_head.0 as ONE 1x1 GEMM over the trunk (N = 64 + 128), round 4
+    NormParams hv_n_;        // their GroupNorm parameters, concatenated
     NormParams ph_n_;
     float logit_scale_ = 1.f;
     PackedGemm vh0_, vh3_, vfc1_, vfc2_, vgate_, vfc3_;

@@ -38,6 +38,7 @@ Net::Net(const m0_net_cfg& cfg, int device, hipStream_t stream) : cfg_(cfg), dev
     // kernel-variant switches (A/B runs): read ONCE, here, so that the layout decisions of forward() and the dispatcher agree
     auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
     sw_.fuse_tail = !off("M0_FUSE_TAIL");     // =0: conv2 + se_gate + ew_board as separate kernels
+    sw_.fuse_small = !off("M0_FUSE_SMALL");   // =0: stem / head convs write raw tensors + statistics for ew_board passes (rounds 1-3)
     sw_.fuse_attn = !off("M0_FUSE_ATTN");     // =0: qkv GEMM + attn_core + proj GEMM + ew_board as separate kernels
     sw_.splitk = !off("M0_SPLITK");           // =0: value_fc1 never splits K
     sw_.conv_zs = !off("M0_CONV_ZS");         // =0: conv_pp16_kernel instead of conv_zs_kernel
@@ -391,6 +392,26 @@ int Net::finalize(std::string& err) {
     TRY(upload_norm(vh1_n_, "value_head.1", 128, 128, err));
     TRY(pack_gemm(vh3_, "value_head.3.weight", "", 1, 128, 128, 128, 128, 0, err));
     TRY(upload_norm(vh4_n_, "value_head.4", 128, 128, err));
+    {   // policy_head.0 (64 channels) and value_head.0 (128) read the same trunk: one GEMM with N = 192, columns [policy | value], both
+        // in the small-tile layout [Cin / 32][N][32]; GroupNorm parameters concatenated the same way
+        const int nch = Cp_ / 32;
+        std::vector<_Float16> a((size_t)nch * 64 * 32), b((size_t)nch * 128 * 32), c((size_t)nch * 192 * 32);
+        (void)hipMemcpy(a.data(), ph_conv_.w, a.size() * 2, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), vh0_.w, b.size() * 2, hipMemcpyDeviceToHost);
+        for (int ch = 0; ch < nch; ++ch) {
+            std::copy(a.begin() + (size_t)ch * 64 * 32, a.begin() + (size_t)(ch + 1) * 64 * 32, c.begin() + (size_t)ch * 192 * 32);
+            std::copy(b.begin() + (size_t)ch * 128 * 32, b.begin() + (size_t)(ch + 1) * 128 * 32, c.begin() + ((size_t)ch * 192 + 64) * 32);
+        }
+        hv_.w = (_Float16*)dalloc(c.size() * 2, false);
+        if (!hv_.w) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+        (void)hipMemcpy(hv_.w, c.data(), c.size() * 2, hipMemcpyHostToDevice);
+        hv_.taps = 1; hv_.Cin = Cp_; hv_.N = 192; hv_.pp = false; hv_.bias = nullptr;
+        std::vector<float> g(192), be(192);
+        (void)hipMemcpy(g.data(), ph_n_.gamma, 64 * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(g.data() + 64, vh1_n_.gamma, 128 * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(be.data(), ph_n_.beta, 64 * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(be.data() + 64, vh1_n_.beta, 128 * 4, hipMemcpyDeviceToHost);
+        hv_n_.gamma = upload_f32(g); hv_n_.beta = upload_f32(be);
+        if (!hv_n_.gamma || !hv_n_.beta) { err = "hipMalloc failed"; return M0_ERR_HIP; }
+    }
     {
         int h1 = 2 * C, h1p = ceil_to(h1, 32), h2 = C, h2p = ceil_to(C, 32);
         TRY(pack_gemm(vfc1_, "value_fc1.weight", "value_fc1.bias", 1, 8192, 8192, h1, h1p, 128, err));
@@ -644,11 +665,23 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
     }
 
     // stem (resnet.py:314-318) + chess features (229-244)
-    KCHK(run_gemm(stem_, x0, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+    // fused small kernels (round 4): GroupNorm + activation (+ positional encoding) in the conv's own epilogue
+    const bool fuse_small = sw_.fuse_small && C % 64 == 0 && (act == ACT_SILU || act == ACT_RELU);
+    auto gn_gemm = [&](const PackedGemm& g, int taps, const _Float16* in, _Float16* out, int ldo, const NormParams& n, const float* pos,
+                       _Float16* out2, int ldo2, int nsplit) -> hipError_t {
+        GemmArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.in = in; ga.w = g.w; ga.out = out; ga.gn_gamma = n.gamma; ga.gn_beta = n.beta; ga.posenc = pos;
+        ga.Mrows = Mc; ga.Mvalid = Mc; ga.Cin = g.Cin; ga.N = g.N; ga.Npad = g.N; ga.ldo = ldo; ga.epi_act = act; ga.out_scale = 1.f;
+        ga.out2 = out2; ga.ldo2 = ldo2; ga.nsplit = nsplit;
+        return launch_conv_gemm(ga, taps, st);
+    };
     _Float16* xa = XA_;
     _Float16* xb = XB_;
+    if (!(fuse_small && cfg_.chess_features)) KCHK(run_gemm(stem_, x0, T1_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
     if (cfg_.chess_features) {
-        KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, posenc_, nullptr, xa, nullptr, nullptr, nullptr, C, Bp));
+        if (fuse_small) KCHK(gn_gemm(stem_, 9, x0, xa, C, stem_n_, posenc_, nullptr, 0, 0));
+        else KCHK(ew(T1_, S1_, &stem_n_, nullptr, nullptr, posenc_, nullptr, xa, nullptr, nullptr, nullptr, C, Bp));
         if (cfg_.piece_square_tables) {
             if (fuse_tail) {
                 // piece-square-table 1x1 conv + GroupNorm/act + residual add in one kernel
@@ -733,9 +766,13 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
             std::swap(xa, xb);
         }
     }
-    // policy head (resnet.py:699-711)
-    KCHK(run_gemm(ph_conv_, xa, PH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(PH_, S1_, &ph_n_, nullptr, nullptr, nullptr, nullptr, PH2_, nullptr, nullptr, nullptr, 64, Bp));
+    // policy head (resnet.py:699-711); fused: its conv and the value head's first conv read the trunk ONCE, GroupNorm + activation in
+    // the epilogue (PH2_ <- policy, VH2_ <- value)
+    if (fuse_small) KCHK(gn_gemm(hv_, 1, xa, PH2_, 64, hv_n_, nullptr, VH2_, 128, 64));
+    else {
+        KCHK(run_gemm(ph_conv_, xa, PH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+        KCHK(ew(PH_, S1_, &ph_n_, nullptr, nullptr, nullptr, nullptr, PH2_, nullptr, nullptr, nullptr, 64, Bp));
+    }
     if (cfg_.policy_factor_rank > 0) {
         KCHK(run_gemm(pfc1_, PH2_, F1_, Mfc, Mfc, nullptr, ACT_RELU, nullptr, nullptr, false, 1.f, st));
         KCHK(run_gemm(pfc2_, F1_, logits_dev, Mfc, B, nullptr, 0, nullptr, nullptr, true, logit_scale_, st));
@@ -743,11 +780,17 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
         KCHK(run_gemm(pfc1_, PH2_, logits_dev, Mfc, B, nullptr, 0, nullptr, nullptr, true, logit_scale_, st));
     }
     // value head (resnet.py:721-734)
-    KCHK(run_gemm(vh0_, xa, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(VH_, S1_, &vh1_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
-    KCHK(run_gemm(vh3_, VH2_, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-    KCHK(ew(VH_, S1_, &vh4_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
-    KCHK(run_gemm(vfc1_, VH2_, F2_, Mfc, Mfc, nullptr, vact, nullptr, nullptr, false, 1.f, st));
+    const _Float16* vflat = VH2_;
+    if (fuse_small) {
+        KCHK(gn_gemm(vh3_, 1, VH2_, VH_, 128, vh4_n_, nullptr, nullptr, 0, 0));
+        vflat = VH_;
+    } else {
+        KCHK(run_gemm(vh0_, xa, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+        KCHK(ew(VH_, S1_, &vh1_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
+        KCHK(run_gemm(vh3_, VH2_, VH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+        KCHK(ew(VH_, S1_, &vh4_n_, nullptr, nullptr, nullptr, nullptr, VH2_, nullptr, nullptr, nullptr, 128, Bp));
+    }
+    KCHK(run_gemm(vfc1_, vflat, F2_, Mfc, Mfc, nullptr, vact, nullptr, nullptr, false, 1.f, st));
     KCHK(run_gemm(vfc2_, F2_, F3_, Mfc, Mfc, nullptr, vact, nullptr, nullptr, false, 1.f, st));
     KCHK(run_gemm(vgate_, F3_, F4_, Mfc, Mfc, nullptr, ACT_SIGMOID, F3_, nullptr, false, 1.f, st));
     KCHK(run_gemm(vfc3_, F4_, VAL_, Mfc, Mfc, nullptr, ACT_TANH, nullptr, nullptr, true, 1.f, st));

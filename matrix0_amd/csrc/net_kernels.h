@@ -41,6 +41,13 @@ struct GemmArgs {
     const _Float16* se_w2h;  //   wave (half the bytes of the f32 matrices, which it brought in one after the other)
     int no_zs;               // 3x3 big tile: 1 = conv_pp16_kernel instead of conv_zs_kernel (M0_CONV_ZS=0, read once per network)
     const void* se_wf;       // conv_zs_kernel's tail: W1 and W2 as fp16 MFMA B-fragment pieces of 1 KiB (conv_zs_tail.h; net.hip packs)
+    // small tile with gn_gamma != null (conv_gemm_kernel, EPI 1): out = epi_act(GroupNorm16(conv)) [+ posenc], fp16, through the
+    // LDS-staged 16-byte-store epilogue.  Two consumers of one input in ONE launch (policy-head and value-head 1x1 convs over the
+    // trunk): columns >= nsplit go to out2 (row stride ldo2, column - nsplit); gn_gamma / gn_beta cover all N columns.
+    const float* posenc;     // [64 squares][N] f32 added after the activation (stem), or null
+    void* out2;
+    int ldo2;
+    int nsplit;
 };
 
 struct EwArgs {

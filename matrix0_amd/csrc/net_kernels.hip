@@ -23,11 +23,16 @@
 //   attn_core_kernel  ChessAttention scores/softmax/PV for one (board, head).
 //   planes_to_nhwc_kernel  f32 [B,19,8,8] -> fp16 [B,64,32].
 #include "kernel_common.h"
+#include "conv_epilogue.h"
 
 // ---------------------------------------------------------------------------
 // conv_gemm
 // ---------------------------------------------------------------------------
-template <int TAPS, int WN, int NT, int KC>
+// EPI 0: bias / runtime activation / gate multiply / scale, fp16 or f32 stored per element, per-(board, channel) sums.
+// EPI 1 (round 4): act<ACT>(GroupNorm16(conv)) [+ positional encoding] applied to the accumulators (a wave holds all 64 squares of
+//        its board for its 32 NT channels = 2 NT whole groups), fp16 through the wave's LDS image in 16-byte stores -- the stem
+//        and the head convs no longer write a raw tensor + statistics for an ew_board pass to read back.
+template <int TAPS, int WN, int NT, int KC, int EPI = 0, int ACT = 0>
 __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     constexpr int NB = WN * NT * 32;      // output channels per workgroup
     constexpr int NTHR = 256 * WN;
@@ -160,6 +165,52 @@ __global__ __launch_bounds__(256 * WN) void conv_gemm_kernel(GemmArgs a) {
     }
 
     // ---------------- epilogue ----------------
+    if constexpr (EPI == 1) {
+        __syncthreads();                                  // every wave has left the operand tiles: the LDS becomes the staging images
+        char* lds_wave = smem + wave * (64 * 64 * NT);
+        const int cb = n0 + wn * NT * 32;                 // first column of this wave's tile
+        const int r31 = lane & 31, half = lane >> 5;
+        GemmArgs o = a;                                   // destination of this wave's columns (conv_stage_flush reads out, ldo, Mvalid)
+        int lc = cb;
+        if (a.out2 != nullptr && cb >= a.nsplit) { o.out = a.out2; o.ldo = a.ldo2; lc = cb - a.nsplit; }
+        o.out = reinterpret_cast<_Float16*>(o.out) + lc;
+        char* wbase = conv_stage_base<NT>(lds_wave, lane);
+        static_for<0, NT>([&](auto ni_) __attribute__((always_inline)) {
+            constexpr int ni = decltype(ni_)::value;
+            const int col = cb + ni * 32 + r31;
+            float s = 0.f, ss = 0.f;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                const float16v av = acc[decltype(mi_)::value][ni];
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) { const float v = av[decltype(r_)::value]; s += v; ss += v * v; });
+            });
+#pragma unroll
+            for (int o2 = 1; o2 <= 8; o2 <<= 1) { s += __shfl_xor(s, o2); ss += __shfl_xor(ss, o2); }
+            s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+            const float mean = s * (1.f / 1024.f);
+            float var = ss * (1.f / 1024.f) - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float g = rsqrtf(var + 1e-5f) * a.gn_gamma[col];
+            const float sh = a.gn_beta[col] - mean * g;
+            static_for<0, 2>([&](auto mi_) __attribute__((always_inline)) {
+                constexpr int mi = decltype(mi_)::value;
+                float v[16];
+                static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_)::value;
+                    v[r] = act_fast<ACT>(acc[mi][ni][r] * g + sh);
+                });
+                if (a.posenc != nullptr) {
+                    static_for<0, 16>([&](auto r_) __attribute__((always_inline)) {
+                        constexpr int r = decltype(r_)::value;
+                        const int sq = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        v[r] += a.posenc[(size_t)sq * a.N + col];
+                    });
+                }
+                conv_stage_tile<NT, mi, ni>(v, wbase, lane);
+            });
+        });
+        conv_stage_flush<NT>(o, lds_wave, m0, 0, wm, 0, lane);
+        return;
+    }
     // (everything indexed with compile-time constants: a runtime-indexed accumulator goes to scratch)
     const int ldo = a.ldo;
     const int rowbase = m0 + wm * 64 + 4 * (lane >> 5);
@@ -209,22 +260,38 @@ static size_t conv_gemm_lds(int Cin) {
     constexpr int AST = KC + 8;
     constexpr int APIX = (TAPS == 9) ? 100 : 64;
     (void)Cin;
-    return (size_t)(4 * APIX * AST + 2 * NB * AST) * 2 + 64;
+    const size_t main_loop = (size_t)(4 * APIX * AST + 2 * NB * AST) * 2 + 64;
+    const size_t staging = (size_t)WN * 4 * 64 * 64 * NT;          // EPI 1: one [64 rows][32 NT] fp16 image per wave
+    return main_loop > staging ? main_loop : staging;
 }
 
-template <int TAPS, int WN, int NT, int KC>
+template <int TAPS, int WN, int NT, int KC, int EPI = 0, int ACT = 0>
 static hipError_t launch_conv_gemm_t(const GemmArgs& a, hipStream_t st) {
     constexpr int NB = WN * NT * 32;
     size_t lds = conv_gemm_lds<TAPS, WN, NT, KC>(a.Cin);
     static DeviceOnce once;
     hipError_t e = once.run([] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<TAPS, WN, NT, KC>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<TAPS, WN, NT, KC, EPI, ACT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (e != hipSuccess) return e;
     dim3 grid(a.Mrows / 256, a.Npad / NB);
-    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, WN, NT, KC>), grid, dim3(256 * WN), lds, st, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, WN, NT, KC, EPI, ACT>), grid, dim3(256 * WN), lds, st, a);
     return hipGetLastError();
+}
+// small tile with the fused GroupNorm epilogue: the stem (3x3, 64 channels per workgroup), one head conv (64 or 128 channels:
+// the whole N in one workgroup, the input rows read once), or the policy-head and value-head convs together (64 + 128 channels,
+// three wave groups, two outputs)
+template <int ACT>
+static hipError_t launch_conv_gemm_gn(const GemmArgs& a, int taps, hipStream_t st) {
+    if (a.bias != nullptr || a.mul != nullptr || a.out_stats != nullptr || a.out_f32 || a.out_scale != 1.f || a.Npad != a.N)
+        return hipErrorInvalidValue;
+    if (taps == 9) return a.Npad % 64 == 0 && a.out2 == nullptr ? launch_conv_gemm_t<9, 1, 2, 32, 1, ACT>(a, st) : hipErrorInvalidValue;
+    if (a.posenc != nullptr) return hipErrorInvalidValue;
+    if (a.out2 != nullptr) return a.Npad == 192 && a.nsplit == 64 ? launch_conv_gemm_t<1, 3, 2, 32, 1, ACT>(a, st) : hipErrorInvalidValue;
+    if (a.Npad == 128) return launch_conv_gemm_t<1, 2, 2, 32, 1, ACT>(a, st);
+    if (a.Npad == 64) return launch_conv_gemm_t<1, 1, 2, 32, 1, ACT>(a, st);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_big(const GemmArgs& a, int taps, hipStream_t st);   // conv_big.hip
@@ -242,7 +309,11 @@ int conv_gemm_kc(int Cin, int Npad) {
 hipError_t launch_conv_gemm(const GemmArgs& a, int taps, hipStream_t st) {
     if (a.Mrows % 256 != 0 || a.Cin % 32 != 0 || a.Npad % 32 != 0) return hipErrorInvalidValue;
     const bool big = conv_gemm_tile_n(a.Cin, a.Npad) == 320;
-    if (a.gn_gamma != nullptr && !big) return hipErrorInvalidValue;   // fused GN epilogue: big tile only
+    if (a.gn_gamma != nullptr && !big) {                              // small tile with the fused GroupNorm epilogue
+        if (a.epi_act == ACT_SILU) return launch_conv_gemm_gn<ACT_SILU>(a, taps, st);
+        if (a.epi_act == ACT_RELU) return launch_conv_gemm_gn<ACT_RELU>(a, taps, st);
+        return hipErrorInvalidValue;
+    }
     if (taps == 9) {
         if (big) {
             if (!a.w_pp) return hipErrorInvalidValue;
