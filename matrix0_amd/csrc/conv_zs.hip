@@ -34,6 +34,16 @@ __device__ __forceinline__ void zs_glds16(const void* gsrc, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// activation pieces: every byte is read once, by one workgroup.  ZS_A_AUX = 2 (nt) asks the caches not to keep them, so that the
+// 1.84 MB of weights every workgroup of an XCD streams stay in that XCD's 4 MB L2 instead of being evicted by the ~10 MB of
+// activations a round of 32 workgroups moves through it (measured: profiles/r04_exp_conv_activation_loads_nt.log)
+#ifndef ZS_A_AUX
+#define ZS_A_AUX 0
+#endif
+__device__ __forceinline__ void zs_glds16_act(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, ZS_A_AUX);
+}
 #define ZS_FENCE() asm volatile("" ::: "memory")
 
 #ifdef SW_STAMP
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
         const int p = 8 * qq + (lane >> 3);             // 1-KiB piece: rows 8qq..8qq+7 of the 256-row tile
         const int key = (p & 2) | (((p >> 6) & 1) << 2);
         const char* src = in_bytes + ((size_t)(m0 + p) * Cin + (size_t)chunk * 64) * 2 + 16 * ((lane & 7) ^ key);
-        zs_glds16(src, A_lds + (chunk & 1) * ZS_A_BYTES + qq * 1024);
+        zs_glds16_act(src, A_lds + (chunk & 1) * ZS_A_BYTES + qq * 1024);
     };
     auto issue_half = [&](int y) __attribute__((always_inline)) {      // prologue only
         const char* src = w_blk + (size_t)(y >> 1) * w_kt_stride + (size_t)(y & 1) * ZS_WH_BYTES;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
         } else {
             const bool have = a_left > 0;
             const uint32_t al = ((8 - a_left) & 2) ? a_lane1 : a_lane0;     // pieces 2, 3, 6, 7 of this wave: odd boards
-            zs_glds16((have ? a_ptr : in_bytes) + al, have ? A_lds + a_dst : D_lds + (wave - 4) * 1024);
+            zs_glds16_act((have ? a_ptr : in_bytes) + al, have ? A_lds + a_dst : D_lds + (wave - 4) * 1024);
             a_ptr += have ? (size_t)32 * Cin * 2 : 0;
             a_dst += have ? 4096 : 0;
             a_left -= have ? 1 : 0;
