@@ -108,6 +108,21 @@ int m0_net_profile_get(m0_net* net, double* conv_ms, double* conv_flop, int64_t*
 int m0_net_profile_get_tail(m0_net* net, double* tail_ms, int64_t* tail_launches);
 
 
+/* ---- optional weight broadcast over RCCL / xGMI (the reference has no counterpart: its workers each read the
+ * checkpoint, selfplay/internal.py:150-190).  One process per GPU.  Rank 0 calls m0_dist_unique_id and ships the 128 bytes to the
+ * other ranks by any out-of-band means (a file, a socket, MPI); every rank calls m0_dist_create (collective: it returns when all
+ * `world` ranks have joined).  m0_net_broadcast_weights (collective) overwrites every packed device buffer of a FINALIZED network
+ * with the root's: the other ranks finalize a network of the same configuration first, with any weights of the right shapes;
+ * networks of different configurations are refused before anything is sent.  librccl is loaded at the first call; without it the
+ * functions fail with M0_ERR_UNSUPPORTED / NULL.  (matrix0_amd/dist.py does the same through torch.distributed.) */
+typedef struct m0_dist m0_dist;
+int m0_dist_unique_id(void* id128);
+m0_dist* m0_dist_create(int rank, int world, const void* id128, int hip_device);
+void m0_dist_destroy(m0_dist* d);
+int m0_dist_rank(const m0_dist* d);
+int m0_dist_world(const m0_dist* d);
+int m0_net_broadcast_weights(m0_net* net, m0_dist* d, int root);
+
 /* ---- position-wise azchess/encoding.py on the device (batched) ----
  * encode_board (encoding.py:11-46), MoveEncoder.get_legal_actions (:231-243), move_to_index (:80-150).
  * fens: n NUL-terminated strings.  Outputs nullable:

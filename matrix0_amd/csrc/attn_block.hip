@@ -325,9 +325,22 @@ __global__ __launch_bounds__(512) void attn_block_kernel(AttnBlockArgs a) {
                 if (type < 2) {
                     *reinterpret_cast<half4v*>(smem + AB_QK + type * 8192 + hl * 4096 + token * 32 + (((lq >> 1) ^ (l15 >> 3)) & 1) * 16 + (lq & 1) * 8) = h;
                 } else {
+                    // V transposed: [unit][dim][token].  Two-byte stores (one per dim and lane) cost ~60 cycles each with all
+                    // waves at it (sub-dword LDS writes); instead neighbouring lanes = neighbouring tokens exchange half of their
+                    // values (DPP), so that the even lane holds dims 4 lq, 4 lq + 1 and the odd lane dims 4 lq + 2, 4 lq + 3 of
+                    // BOTH tokens: two 4-byte stores per lane, the same bytes in the same places
                     const int unit = (token >> 6) * 2 + hl, sq = token & 63;
-                    _Float16* vt = reinterpret_cast<_Float16*>(smem + AB_VT) + (unit * 16 + 4 * lq) * AB_VROW + sq;
-                    vt[0] = h[0]; vt[AB_VROW] = h[1]; vt[2 * AB_VROW] = h[2]; vt[3 * AB_VROW] = h[3];
+                    union { half2v h2; uint32_t u; } p01, p23;
+                    p01.h2 = half2v{h[0], h[1]}; p23.h2 = half2v{h[2], h[3]};
+                    const bool odd = (lane & 1) != 0;
+                    const uint32_t own = odd ? p23.u : p01.u;
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? p01.u : p23.u), 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                    const uint32_t ta = odd ? recv : own, tb = odd ? own : recv;          // first / second token of the pair
+                    const uint32_t w0 = __builtin_amdgcn_perm(tb, ta, 0x05040100u);       // (dim r, token), (dim r, token + 1)
+                    const uint32_t w1 = __builtin_amdgcn_perm(tb, ta, 0x07060302u);       // dim r + 1
+                    uint32_t* vt = reinterpret_cast<uint32_t*>(reinterpret_cast<_Float16*>(smem + AB_VT) +
+                                                               (unit * 16 + 4 * lq + (odd ? 2 : 0)) * AB_VROW + (sq & ~1));
+                    vt[0] = w0; vt[AB_VROW / 2] = w1;
                 }
             });
         });

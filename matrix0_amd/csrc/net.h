@@ -68,6 +68,11 @@ public:
     int load(const char* name, const void* data, int dtype, const int64_t* shape, int ndim, std::string& err);
     int finalize(std::string& err);
     bool ready() const { return finalized_; }
+    // every device buffer finalize() made (packed GEMM weights, norm parameters, bias / mask tables), in creation order: the same
+    // list with the same sizes on every process that finalized a network of the same configuration
+    const std::vector<void*>& device_buffers() const { return dev_allocs_; }
+    const std::vector<size_t>& device_buffer_bytes() const { return dev_sizes_; }
+
     // planes: device f32 [B][planes][64] (planes_dev) or device fp16 NHWC [B][64][32] (nhwc_dev)
     // outputs (device): logits f32 [B][4672], value f32 [B]; ssl (optional) f32 concatenated
     int forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float* logits_dev, float* value_dev,
@@ -100,6 +105,7 @@ private:
     size_t nparams_ = 0;
     std::map<std::string, HostTensor> sd_;
     std::vector<void*> dev_allocs_;
+    std::vector<size_t> dev_sizes_;          // bytes of dev_allocs_[i] (m0_net_broadcast_weights ships them in this order)
     std::vector<void*> ws_allocs_;
 
     int C_ = 0, Cs_ = 0 /*ssl hidden padded*/;

@@ -75,6 +75,7 @@ void* Net::dalloc(size_t bytes, bool ws) {
     (void)hipMemsetAsync(p, 0, bytes, stream_);
     if (!ws) (void)hipStreamSynchronize(stream_);
     (ws ? ws_allocs_ : dev_allocs_).push_back(p);
+    if (!ws) dev_sizes_.push_back(bytes);
     return p;
 }
 

@@ -68,3 +68,62 @@ def reduce_clock_and_counters(seconds: float, counters: np.ndarray, device: Opti
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), c.cpu().numpy()
+
+
+# ---- the same broadcast without torch.distributed: the C-ABI entry points of csrc/capi_dist.hip (RCCL loaded by the library) ----
+class CAbiDist:
+    """One communicator per process (m0_dist_create).  `id128` comes from `CAbiDist.unique_id()` on rank 0 and reaches the other
+    ranks by any out-of-band means -- a file on a shared path in `CAbiDist.from_file`."""
+
+    def __init__(self, rank: int, world: int, id128: bytes, device_index: int = 0):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        L.m0_dist_create.restype = C.c_void_p
+        L.m0_dist_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.m0_dist_destroy.argtypes = [C.c_void_p]
+        L.m0_net_broadcast_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if len(id128) != 128:
+            raise ValueError("id128 must be the 128 bytes of m0_dist_unique_id")
+        self._L = L
+        self._h = L.m0_dist_create(int(rank), int(world), bytes(id128), int(device_index))
+        if not self._h:
+            raise RuntimeError("m0_dist_create: " + L.m0_last_error().decode())
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        buf = C.create_string_buffer(128)
+        _lib.check(L.m0_dist_unique_id(buf), "m0_dist_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_file(cls, path: str, rank: int, world: int, device_index: int = 0, timeout_s: float = 120.0) -> "CAbiDist":
+        """Rank 0 writes the id to `path` (atomically), the others wait for it."""
+        import os
+        import time
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(cls.unique_id())
+            os.replace(tmp, path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"no communicator id at {path}")
+            time.sleep(0.05)
+        with open(path, "rb") as f:
+            return cls(rank, world, f.read(), device_index)
+
+    def broadcast_weights(self, backend, root: int = 0) -> None:
+        """Every packed device buffer of `backend` (an M0Backend whose weights are finalized) becomes the root's."""
+        from . import _lib
+        _lib.check(self._L.m0_net_broadcast_weights(backend._h, self._h, int(root)), "m0_net_broadcast_weights")
+
+    def close(self) -> None:
+        if self._h:
+            self._L.m0_dist_destroy(self._h)
+            self._h = None

@@ -399,3 +399,25 @@ def test_infer_np_rejects_bad_shape_and_nan():
     bad[0, 0, 0, 0] = np.nan
     with pytest.raises(ValueError):
         be.infer_np(bad)
+
+
+def test_cabi_weight_broadcast_single_rank_and_guards():
+    """m0_dist_* / m0_net_broadcast_weights (the RCCL broadcast without torch, csrc/capi_dist.hip) with a one-rank communicator:
+    the collective runs, the network computes what it computed before, and a network that is not finalized is refused.
+    (The driver's multi-GPU node exercises more ranks; ranks = GPUs, and this box has one.)"""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd.dist import CAbiDist
+    from matrix0_amd import _lib
+    cfg, sd, x, *_ = load_net_golden("gn_silu_preact")
+    be = M0Backend.from_state_dict(cfg, sd)
+    p0, v0 = be.infer_np(x)
+    d = CAbiDist(0, 1, CAbiDist.unique_id(), 0)
+    d.broadcast_weights(be, root=0)
+    p1, v1 = be.infer_np(x)
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    raw = M0Backend(cfg)                      # created, weights not loaded / finalized
+    with pytest.raises(RuntimeError, match="finalized"):
+        d.broadcast_weights(raw, root=0)
+    with pytest.raises(ValueError):
+        d.broadcast_weights(be, root=3)       # no such rank
+    raw.close(); d.close(); be.close()
