@@ -800,9 +800,14 @@ int Net::forward(const float* planes_dev, const _Float16* nhwc_dev, int B, float
     if (ssl_dev && !ssl_.empty()) {
         const int ctot = ssl_channels_total();
         int coff = 0;
+        const bool ssl_fused = fuse_small && (Cs_ == 160 || Cs_ == 128 || Cs_ == 64 || Cs_ == 32);
         for (auto& h : ssl_) {
-            KCHK(run_gemm(h.c0, xa, SH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
-            KCHK(ew(SH_, S1_, &h.n, nullptr, nullptr, nullptr, nullptr, SH2_, nullptr, nullptr, nullptr, Cs_, Bp));
+            if (ssl_fused) {        // the head's first conv with GroupNorm + activation in its epilogue, all its channels in one workgroup
+                KCHK(gn_gemm(h.c0, 1, xa, SH2_, Cs_, h.n, nullptr, nullptr, 0, 0));
+            } else {
+                KCHK(run_gemm(h.c0, xa, SH_, Mc, Mc, nullptr, 0, nullptr, S1_, false, 1.f, st));
+                KCHK(ew(SH_, S1_, &h.n, nullptr, nullptr, nullptr, nullptr, SH2_, nullptr, nullptr, nullptr, Cs_, Bp));
+            }
             KCHK(run_gemm(h.c1, SH2_, SO_, Mc, Mc, nullptr, 0, nullptr, nullptr, false, 1.f, st));
             KCHK(launch_nhwc_to_nchw_f32(SO_, ssl_dev, B, 32, h.out_ch, ctot, coff, st));
             coff += h.out_ch;

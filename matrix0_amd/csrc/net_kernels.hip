@@ -289,8 +289,10 @@ static hipError_t launch_conv_gemm_gn(const GemmArgs& a, int taps, hipStream_t s
     if (taps == 9) return a.Npad % 64 == 0 && a.out2 == nullptr ? launch_conv_gemm_t<9, 1, 2, 32, 1, ACT>(a, st) : hipErrorInvalidValue;
     if (a.posenc != nullptr) return hipErrorInvalidValue;
     if (a.out2 != nullptr) return a.Npad == 192 && a.nsplit == 64 ? launch_conv_gemm_t<1, 3, 2, 32, 1, ACT>(a, st) : hipErrorInvalidValue;
+    if (a.Npad == 160) return launch_conv_gemm_t<1, 1, 5, 32, 1, ACT>(a, st);      // SSL head convs of the 320-wide trunk
     if (a.Npad == 128) return launch_conv_gemm_t<1, 2, 2, 32, 1, ACT>(a, st);
     if (a.Npad == 64) return launch_conv_gemm_t<1, 1, 2, 32, 1, ACT>(a, st);
+    if (a.Npad == 32) return launch_conv_gemm_t<1, 1, 1, 32, 1, ACT>(a, st);
     return hipErrorInvalidValue;
 }
 
