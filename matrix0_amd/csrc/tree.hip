@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "tree.h"
+#include "kernel_common.h"   // DeviceOnce
 
 using namespace m0;
 
@@ -252,7 +253,9 @@ __device__ float np_sum_f32_dev(const float* a, int n) {
 // MCTS._backpropagate (mcts.py:946-953): the leaf gets +v, its parent -v, ...  The nodes of a path are distinct, so
 // every level is independent: lane d updates level d (all levels' loads in flight at once instead of a chain of
 // dependent read-modify-writes by one lane); the arithmetic per node is that of the sequential loop (negation is exact).
-__device__ void backprop(const Arena& A, const int* path, int depth, double value, int lane, bool may_repeat = false) {   // whole-wave caller
+// (Ln / Lq / ncached: select_kernel's LDS copies of n and q for the nodes below ncached get the very values that go to the arena)
+__device__ void backprop(const Arena& A, const int* path, int depth, double value, int lane, bool may_repeat = false,
+                         int* Ln = nullptr, double* Lq = nullptr, int ncached = 0) {   // whole-wave caller
     const double v = fmax(-1.0, fmin(1.0, value));
     if (may_repeat) {
         // tt_merge: a path can pass through the same node twice (a position repeated along the line); the reference's
@@ -280,7 +283,9 @@ __device__ void backprop(const Arena& A, const int* path, int depth, double valu
         const int nd = path[d];
         const int nn = A.n[nd] + 1;
         const double ww = A.w[nd] + (((depth - d) & 1) ? -v : v);
-        A.n[nd] = nn; A.w[nd] = ww; A.q[nd] = ww / (double)nn;
+        const double qq = ww / (double)nn;
+        A.n[nd] = nn; A.w[nd] = ww; A.q[nd] = qq;
+        if (nd < ncached) { Ln[nd] = nn; Lq[nd] = qq; }
     }
 }
 
@@ -320,7 +325,25 @@ __device__ __forceinline__ size_t tt_table_of(const TreeDev& d, int g, const Gam
     return ((size_t)g * d.tt_sides + (d.tt_sides == 2 ? gd->arena : 0)) * (size_t)d.tt_cap;
 }
 
+// The top of a game's tree lives in LDS for the duration of a select launch (north star: "tree walk over LDS-resident node
+// arrays"): after every played move the kept subtree is compacted BREADTH-FIRST (advance_kernel), so the nodes with the lowest
+// indices are the root, its children, their children ... -- the levels every one of the pass's 96 descents walks through.  The
+// first M0_SEL_CACHE nodes' select fields (prior, q, n, in-flight count, child block, child count, move: 32 B per node) are
+// copied once per launch; the children scan reads them from LDS instead of paying a global round trip per level, and the two
+// things a select launch writes to such nodes (in-flight counts, the statistics of a terminal leaf's path) are written through.
+// Deeper nodes -- and everything in the table modes, whose arenas are not compacted -- are read from the arenas in HBM as before.
+constexpr int M0_SEL_CACHE = 2048;
+constexpr int M0_SEL_CACHE_BYTES = M0_SEL_CACHE * 32;
+
 __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
+    extern __shared__ __attribute__((aligned(16))) char sel_cache[];
+    double* const L_prior = reinterpret_cast<double*>(sel_cache);
+    double* const L_q = L_prior + M0_SEL_CACHE;
+    int* const L_n = reinterpret_cast<int*>(L_q + M0_SEL_CACHE);
+    int* const L_vl = L_n + M0_SEL_CACHE;
+    int* const L_cb = L_vl + M0_SEL_CACHE;
+    int16_t* const L_nch = reinterpret_cast<int16_t*>(L_cb + M0_SEL_CACHE);
+    uint16_t* const L_mv = reinterpret_cast<uint16_t*>(L_nch + M0_SEL_CACHE);
     __shared__ uint64_t pkey[M0_MAX_DEPTH];
     __shared__ uint8_t pirr[M0_MAX_DEPTH];
     __shared__ Move smoves[M0_MAX_MOVES];
@@ -378,6 +401,16 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
     int nleaf = gd->sims_target - gd->sims_done;
     if (nleaf > d.L) nleaf = d.L;
     if (nleaf < 0) nleaf = 0;
+    // the top of the tree -> LDS (after the Dirichlet noise, which rewrites the root's priors)
+    int ncached = 0;
+    if (!c.tt_merge && nleaf > 0) {
+        ncached = gd->next < M0_SEL_CACHE ? gd->next : M0_SEL_CACHE;
+        for (int i = lane; i < ncached; i += 64) {
+            L_prior[i] = A.prior[i]; L_q[i] = A.q[i]; L_n[i] = A.n[i]; L_vl[i] = A.vl[i]; L_cb[i] = A.cbase[i];
+            L_nch[i] = A.nch[i]; L_mv[i] = A.mv[i];
+        }
+        __syncthreads();
+    }
     uint64_t ctrj = gd->ctr_jitter;
     const uint64_t seedj = gd->seed_jitter;
     const double jit = c.selection_jitter > 0.0 ? c.selection_jitter : 0.001;
@@ -393,8 +426,9 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
         if (lane == 0) { path[0] = root; if (epath) epath[0] = root; }
         // One round of dependent loads per level: the children scan also fetches every candidate's own node fields
         // (children ARE nodes), and the winner's are broadcast -- the next level starts without loading its node.
-        int nc = A.nch[node], cb = A.cbase[node], nn = A.n[node];
-        double nq = A.q[node];
+        const bool rh = node < ncached;
+        int nc = rh ? (int)L_nch[node] : (int)A.nch[node], cb = rh ? L_cb[node] : A.cbase[node], nn = rh ? L_n[node] : A.n[node];
+        double nq = rh ? L_q[node] : A.q[node];
         while (true) {
             if (nc <= 0 || depth >= M0_MAX_DEPTH - 1) break;
             const double sq = sqrt((double)(nn > 1 ? nn : 1));
@@ -406,17 +440,19 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             Move b_mv = 0;
             for (int i = lane; i < nc; i += 64) {
                 const int ci = cb + i;
-                const int cn = A.n[ci];
-                const double cq = A.q[ci];
-                const int c_nch = A.nch[ci], c_cb = A.cbase[ci];
-                const Move m = A.mv[ci];
+                const bool hit = ci < ncached;                  // the children of a node are one block: all lanes agree but at the edge
+                const int cn = hit ? L_n[ci] : A.n[ci];
+                const double cq = hit ? L_q[ci] : A.q[ci];
+                const int c_nch = hit ? (int)L_nch[ci] : (int)A.nch[ci], c_cb = hit ? L_cb[ci] : A.cbase[ci];
+                const Move m = hit ? (Move)L_mv[ci] : A.mv[ci];
+                const double cprior = hit ? L_prior[ci] : A.prior[ci];
                 const double qq = cn == 0 ? nq - c.fpu_reduction : cq;
-                const double u = eff * A.prior[ci] * (sq / (1.0 + (double)cn));
+                const double u = eff * cprior * (sq / (1.0 + (double)cn));
                 double sc = qq + u;
                 if (c.no_instant_backtrack && depth >= 1) {
                     if (mv_from(m) == prev_to && mv_to(m) == prev_from) sc -= 0.01;
                 }
-                const int cvl = c.virtual_loss_active ? A.vl[ci] : 0;
+                const int cvl = c.virtual_loss_active ? (hit ? L_vl[ci] : A.vl[ci]) : 0;
                 if (c.virtual_loss_active && c.virtual_loss > 0.0) sc -= (double)cvl * c.virtual_loss;
                 sc += (u01(seedj, ctrj + (uint64_t)i) - 0.5) * jit;
                 if (sc > best) { best = sc; bi = i; b_nch = c_nch; b_cb = c_cb; b_n = cn; b_q = cq; b_mv = m; b_vl = cvl; }
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             // the scanned in-flight count + 1 (no second load), and no barrier per level: nothing a level stores
             // (in-flight count, path, position keys) is read before the walk has ended
             const int vlw = __shfl(b_vl, wl);
-            if (lane == 0 && c.virtual_loss_active) A.vl[child] = vlw + 1;
+            if (lane == 0 && c.virtual_loss_active) { A.vl[child] = vlw + 1; if (child < ncached) L_vl[child] = vlw + 1; }
             prev_from = mv_from(m); prev_to = mv_to(m);
             node = child; ++depth;
             if (c.tt_merge) {
@@ -522,7 +558,15 @@ __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
             S[s] = smp;
         }
         __syncthreads();                                 // path[] (lane 0) before the wave reads it
-        if (term) { backprop(A, path, depth, tv, lane, c.tt_merge != 0); __syncthreads(); }   // mcts.py:747-751: terminal leaves back up immediately
+        if (term) {                                      // mcts.py:747-751: terminal leaves back up immediately
+            backprop(A, path, depth, tv, lane, c.tt_merge != 0, L_n, L_q, ncached);   // (the cached copies of the path's statistics follow)
+            __syncthreads();
+            // Later descents of this launch read these nodes' statistics again, the uncached ones from the arena: drop this CU's
+            // vector-L1 lines so that they come from L2, where the stores above are.  (Round 4: a load of the same addresses
+            // issued right after the barrier returned the OLD values from time to time -- the lines were resident from the
+            // children scan and a store does not refresh them at once; seen as run-to-run differences in whole games.)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
     }
     if (reinfer) emit_reinfer(nleaf);
     if (lane == 0) { gd->ctr_jitter = ctrj; gd->nsamples = nleaf + (reinfer ? 1 : 0); }
@@ -975,7 +1019,12 @@ __global__ __launch_bounds__(64) void advance_kernel(TreeDev d, const int* game_
 }
 
 hipError_t launch_select(const TreeDev& d, const TreeCfg& c, hipStream_t st) {
-    hipLaunchKernelGGL(select_kernel, dim3(d.G), dim3(64), 0, st, d, c);
+    static DeviceOnce once;
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, M0_SEL_CACHE_BYTES);
+    });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_kernel, dim3(d.G), dim3(64), M0_SEL_CACHE_BYTES, st, d, c);
     return hipGetLastError();
 }
 hipError_t launch_expand(const TreeDev& d, const TreeCfg& c, hipStream_t st) {
