@@ -127,7 +127,7 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
     unsigned long long ts2[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     A4_ST(0, 0); A4_ST(1, 0);
-#ifdef A4_PRIO
+#ifndef A4_NO_PRIO
     if (w & 4) __builtin_amdgcn_s_setprio(1);           // waves 4-7 / 12-15: the later-dispatched wave of each role on its SIMD
 #endif
 
@@ -146,19 +146,45 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
     // 28-31}, ...: chunk ^ (4 - quad) & 3 gives the 16 lanes of a group 16 different bank quads
     const uint32_t wpo = (uint32_t)(l15 * 64 + ((lq ^ (4 - (l15 >> 2))) & 3) * 16);
     const uint32_t orow_a = lds0 + A4_O + token * 640;
-    // one proj piece: k-step g (the two heads of group g) of this wave's 160 channels
-    auto proj_piece = [&](const uint32_t pbase, const int g) __attribute__((always_inline)) {
-        half8 of, pw[10];
-        const int c = 4 * g + lq;
-        a4_lds16<0>(of, orow_a + (uint32_t)(((c & ~7) | ((c ^ tsw) & 7)) * 16));
-        static_for<0, 10>([&](auto jj_) __attribute__((always_inline)) { constexpr int jj = decltype(jj_)::value; a4_lds16<jj * 1024>(pw[jj], pbase + wpo); });
-        static_for<0, 10>([&](auto jj_) __attribute__((always_inline)) {
-            constexpr int jj = decltype(jj_)::value;
-            a4_arrived<9 - jj>(pw[jj]);
-            if constexpr (jj == 0) asm volatile("" : "+v"(of));             // read before pw[0]: there by now
-            oc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pw[jj], of, oc[jj], 0, 0, 0);
+    // proj pieces: k-step g (the two heads of group g) of this wave's 160 channels, ten MFMAs each.  A run of NPC pieces (all in the
+    // ring: the pieces of one interval) is software-pipelined in halves of 5 channel tiles: the fragments of half h + 1 are read
+    // while the MFMAs of half h are issued.
+    auto proj_run = [&](auto npc_, const uint32_t pb0, const uint32_t pb1, const int g0, const int g1) __attribute__((always_inline)) {
+        constexpr int NPC = decltype(npc_)::value, NH = 2 * NPC;
+        half8 of[2], pw[2][5];
+        auto load = [&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value, S = h & 1, pc = h >> 1;
+            const uint32_t pbase = (pc ? pb1 : pb0) + wpo;
+            if constexpr ((h & 1) == 0) {
+                const int c = 4 * (pc ? g1 : g0) + lq;
+                a4_lds16<0>(of[pc], orow_a + (uint32_t)(((c & ~7) | ((c ^ tsw) & 7)) * 16));
+            }
+            static_for<0, 5>([&](auto jj_) __attribute__((always_inline)) {
+                constexpr int jj = decltype(jj_)::value;
+                a4_lds16<(5 * (h & 1) + jj) * 1024>(pw[S][jj], pbase);
+            });
+        };
+        load(std::integral_constant<int, 0>{});
+        static_for<0, NH>([&](auto h_) __attribute__((always_inline)) {
+            constexpr int h = decltype(h_)::value, S = h & 1, pc = h >> 1;
+            if constexpr (h + 1 < NH) {
+                load(std::integral_constant<int, h + 1>{});
+                // the fragments of half h are there once at most the reads of half h + 1 are outstanding (5, +1 with its O fragment)
+                if constexpr (((h + 1) & 1) == 0) a4_arrived5<6>(pw[S][0], pw[S][1], pw[S][2], pw[S][3], pw[S][4]);
+                else a4_arrived5<5>(pw[S][0], pw[S][1], pw[S][2], pw[S][3], pw[S][4]);
+            } else {
+                a4_arrived5<0>(pw[S][0], pw[S][1], pw[S][2], pw[S][3], pw[S][4]);
+            }
+            asm volatile("" : "+v"(of[pc]));
+            static_for<0, 5>([&](auto jj_) __attribute__((always_inline)) {
+                constexpr int jj = decltype(jj_)::value;
+                oc[5 * (h & 1) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pw[S][jj], of[pc], oc[5 * (h & 1) + jj], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
         });
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto proj_piece = [&](const uint32_t pbase, const int g) __attribute__((always_inline)) {
+        proj_run(std::integral_constant<int, 1>{}, pbase, pbase, g, g);
     };
 
     if (w < 8) {
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
             };
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             scores(I0{});
-#ifdef A4_CHUNK_B       // all scores in the first interval (the G-waves' lightest: no staging writes), the rest split over the other two
+#ifndef A4_CHUNK_A      // all scores in the first interval (the G-waves' lightest: no staging writes), the rest split over the other two
             scores(I1{});
             sync();
 #else
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
 #pragma unroll 1
             for (int g = 1; g < 4; ++g) { sb = sync(); proj_piece(sb + A4_PIECE, g); }
 #pragma unroll 1
-            for (int g = 4; g < 10; g += 2) { sb = sync(); proj_piece(sb, g); proj_piece(sb + A4_PIECE, g + 1); }
+            for (int g = 4; g < 10; g += 2) { sb = sync(); proj_run(std::integral_constant<int, 2>{}, sb, sb + A4_PIECE, g, g + 1); }
             static_for<0, 10>([&](auto j_) __attribute__((always_inline)) {     // (every sync since the request waited vmcnt(0))
                 constexpr int j = decltype(j_)::value;
                 asm volatile("" : "+v"(xr[j]));
@@ -415,11 +441,22 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
             *reinterpret_cast<half4v*>(base + stq) = held[0];
             *reinterpret_cast<half4v*>(base + 4096 + stq) = held[1];
         };
+        // V transposed: [unit][dim][token].  Neighbouring lanes = neighbouring tokens exchange half of their values (DPP), so that the
+        // even lane holds dims 4 lq, 4 lq + 1 and the odd lane dims 4 lq + 2, 4 lq + 3 of BOTH tokens: two 4-byte stores per lane
+        // instead of four 2-byte ones (sub-dword LDS stores cost ~60 cycles each with all waves at them)
         auto write_v = [&](auto hl_, const half4v h) __attribute__((always_inline)) {
             constexpr int hl = decltype(hl_)::value;
             const int unit = (token >> 6) * 2 + hl, sq = token & 63;
-            _Float16* vt = reinterpret_cast<_Float16*>(smem + A4_VT) + (unit * 16 + 4 * lq) * A4_VROW + sq;
-            vt[0] = h[0]; vt[A4_VROW] = h[1]; vt[2 * A4_VROW] = h[2]; vt[3 * A4_VROW] = h[3];
+            union { half2v h2; uint32_t u; } p01, p23;
+            p01.h2 = half2v{h[0], h[1]}; p23.h2 = half2v{h[2], h[3]};
+            const bool odd = (lane & 1) != 0;
+            const uint32_t own = odd ? p23.u : p01.u;
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? p01.u : p23.u), 0xB1, 0xF, 0xF, true);   // lane ^ 1
+            const uint32_t ta = odd ? recv : own, tb = odd ? own : recv;          // first / second token of the pair
+            const uint32_t w0 = __builtin_amdgcn_perm(tb, ta, 0x05040100u);       // (dim r, token), (dim r, token + 1)
+            const uint32_t w1 = __builtin_amdgcn_perm(tb, ta, 0x07060302u);       // dim r + 1
+            uint32_t* vt = reinterpret_cast<uint32_t*>(reinterpret_cast<_Float16*>(smem + A4_VT) + (unit * 16 + 4 * lq + (odd ? 2 : 0)) * A4_VROW + (sq & ~1));
+            vt[0] = w0; vt[A4_VROW / 2] = w1;
         };
         // one interval of the qkv GEMM of a head group: channel tiles 2 I and 2 I + 1 (I = 0: q of the two heads, 1: k, 2: v), each
         // ten MFMAs over the whole K into one accumulator; the fragments of a half piece (5 k-steps) are read while the MFMAs of the
@@ -532,7 +569,7 @@ __global__ __launch_bounds__(A4_THREADS) void attn_block4_kernel(AttnBlockArgs a
 #pragma unroll 1
             for (int g = 0; g < 6; g += 2) {
                 if (g) sb = sync();
-                proj_piece(sb, g); proj_piece(sb + A4_PIECE, g + 1);
+                proj_run(std::integral_constant<int, 2>{}, sb, sb + A4_PIECE, g, g + 1);
             }
 #pragma unroll 1
             for (int g = 6; g < 10; ++g) { sb = sync(); proj_piece(sb, g); }
