@@ -199,6 +199,10 @@ def main():
                     help="independent engines (own network instance and HIP stream) sharing the games of a GPU; 2 gives "
                          "+3..4 %% games/s, but per-launch kernel timings then include the other stream's kernels, so the "
                          "roofline of the default run is taken with 1")
+    ap.add_argument("--tail-split", action="store_true",
+                    help="engine.tail_split: evaluate a pass as a whole number of workgroup rounds + a concurrent tail on a second "
+                         "instance over the same weights (bit-identical games; +0.4..0.5 %% measured, and the event-bracketed conv "
+                         "times then include the tail's workgroups, so the default bench keeps one forward per pass)")
     ap.add_argument("--cu-split", action="store_true",
                     help="experiment (with --streams 2): the two engines' streams run on complementary CU halves of every XCD")
     args = ap.parse_args()
@@ -267,7 +271,8 @@ def main():
     def measure(eval_cache: bool):
         """One engine, warm-up, then the timed region of exactly `--steps` searched plies per resident game."""
         kw = dict(concurrent_games=args.games, total_games=0, first_game_index=first_index, leaves_per_step=args.leaves,
-                  virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache)
+                  virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache,
+                  tail_split=args.tail_split)
         if args.streams > 1:
             made = [be]
             e = eng.SelfplayPool(lambda: made.pop() if made else make_backend(),
@@ -309,9 +314,10 @@ def main():
         else:
             e.close()
         d = {k: s1[k] - s0[k] for k in ("steps", "evals", "sims", "plies", "games_finished", "ms_net", "ms_tree", "ms_host",
-                                        "ms_total", "evals_cached")}
+                                        "ms_total", "evals_cached", "rows_tail")}
         counters = np.array([d["evals"], d["plies"], d["games_finished"], conv_ms, conv_flop, conv_launches,
-                             d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed, d["evals_cached"]], dtype=np.float64)
+                             d["ms_net"], d["ms_tree"], d["ms_host"], d["sims"], passes_timed, d["evals_cached"], d["rows_tail"]],
+                            dtype=np.float64)
         dt_max, tot = m0dist.reduce_clock_and_counters(dt, counters, device=torch.device("cuda", local_rank))
         return dt_max, [float(x) for x in tot], tail
 
@@ -320,7 +326,7 @@ def main():
     # and reported beside `value` in `eval_cache` (--no-eval-cache: skip that; --eval-cache-in-value: `value` itself with it on)
     primary_cache = bool(args.eval_cache_in_value)
     dt_max, tot, tail_prof = measure(primary_cache)
-    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all, cached = tot
+    evals, plies, gfin, conv_ms, conv_flop, conv_launches, ms_net, ms_tree, ms_host, sims, passes_all, cached, rows_tail = tot
     passes = max(1.0, passes_all / args.gpus)           # passes per rank in the timed region
     second = None
     if not args.no_eval_cache and not primary_cache:
@@ -349,7 +355,7 @@ def main():
         traffic = None
         try:        # PMC bytes per launch at the profiled batch, scaled to this run's boards per launch (HBM traffic is per board)
             ct = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
-            boards_per_launch = evals / max(1.0, args.gpus * passes)
+            boards_per_launch = (evals - rows_tail) / max(1.0, args.gpus * passes)      # the timed launches: the main instance's
             traffic = int(ct["hbm_bytes_per_launch"] * boards_per_launch / float(ct.get("boards_per_launch", 4096)))
         except Exception:
             pass
@@ -366,6 +372,11 @@ def main():
                        "games_basis": basis, "parallelism": f"games sharded x{args.gpus} (no data-path collective)"
                        + (f", {args.streams} engines / streams per GPU (kernel timings overlap)" if args.streams > 1 else "")},
             "evals_per_s": evals / dt_max, "sims_per_s": sims / dt_max, "plies_per_s": plies / dt_max, "games_finished": int(gfin),
+            # engine.tail_split: a pass = a whole number of workgroup rounds on the main instance + the remaining < 1024 boards on a
+            # second instance over the same weights, at the same time (results unchanged: the forward is bitwise batch invariant).
+            # `roofline` is taken from the main instance's launches (their FLOP over their event time); the tail's convs run inside
+            # those windows on CUs the main launches would have left idle.
+            "tail_split": {"on": bool(args.tail_split), "share_of_evaluations": rows_tail / max(1.0, evals)},
             # second timed region of the same K plies with the product default engine.eval_cache on (module docstring)
             "eval_cache": (None if second is None and not primary_cache else (
                 {"in_value": True, "evaluations_from_cache": int(cached), "share_of_leaf_evaluations": cached / max(1.0, cached + evals)}

@@ -199,6 +199,11 @@ typedef struct m0_selfplay_cfg {
      * also match the stored legal-move count and a checksum of the legal moves; otherwise it is served as a miss.  0 = off. */
     int eval_cache;
     int eval_cache_entries;       /* entries per game (rounded up to a power of two, 4-way sets); 0 = 16384 */
+    /* 1 = a pass of >= 2048 rows on the 320-wide network is evaluated as a main part that is a whole number of rounds of
+     * workgroups (a multiple of 1024 boards) plus a tail (< 1024 boards) on a second instance over the same weights, on its own
+     * stream, at the same time: the tower is board-local, and the tail's workgroups run on the CUs the main launches' partial last
+     * round would leave idle.  Results are unchanged (the forward is bitwise batch invariant).  Self-play engines only. */
+    int tail_split;
 } m0_selfplay_cfg;
 
 typedef struct m0_selfplay m0_selfplay;
@@ -210,6 +215,7 @@ typedef struct m0_selfplay_stats {
     uint64_t ssl_dropped;         /* finished games emitted WITHOUT ssl_* targets because their staging buffers could not grow */
     uint64_t evals_cached;        /* leaf evaluations served by the evaluation cache (not counted in `evals`) */
     int active_games;
+    uint64_t rows_tail;           /* of `evals`: rows evaluated by the tail instance (cfg.tail_split) */
 } m0_selfplay_stats;
 
 /* One finished game = one NPZ shard of the reference (selfplay/internal.py:628-651). Arrays stay valid

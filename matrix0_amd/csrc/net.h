@@ -64,6 +64,10 @@ public:
     // `stream`: the HIP stream every forward of this network runs on (allocations are cleared on it)
     explicit Net(const m0_net_cfg& cfg, int device, hipStream_t stream);
     ~Net();
+    // A second instance over the SAME device weights (read-only after finalize) with its own stream and its own workspace: the
+    // self-play engine evaluates the partial last round of a pass on it beside the main forward (selfplay.hip, tail split).  The
+    // view owns no weights: it must not outlive the network it was made from.
+    Net* shared_view(hipStream_t stream) const;
     static const char* check_supported(const m0_net_cfg& cfg);
     int load(const char* name, const void* data, int dtype, const int64_t* shape, int ndim, std::string& err);
     int finalize(std::string& err);

@@ -60,6 +60,17 @@ Net::Net(const m0_net_cfg& cfg, int device, hipStream_t stream) : cfg_(cfg), dev
     }
 }
 
+Net* Net::shared_view(hipStream_t stream) const {
+    Net* v = new Net(*this);                 // member-wise copy: the packed-weight descriptors point at this network's buffers
+    v->stream_ = stream;
+    v->dev_allocs_.clear(); v->dev_sizes_.clear();          // not owned
+    v->ws_allocs_.clear(); v->wsB_ = 0; v->wsM_ = 0;         // own workspace, allocated at its first forward
+    v->sd_.clear();
+    v->pev_.clear(); v->pflop_.clear(); v->ptail_.clear(); v->pev_used_ = 0; v->profile_ = false;
+    v->prof_ms_ = v->prof_flop_ = v->prof_tail_ms_ = 0; v->prof_launches_ = v->prof_tail_launches_ = 0;
+    return v;
+}
+
 Net::~Net() {
     for (hipEvent_t e : pev_) (void)hipEventDestroy(e);
     for (void* p : dev_allocs_) (void)hipFree(p);

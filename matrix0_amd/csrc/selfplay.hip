@@ -65,6 +65,9 @@ struct m0_selfplay {
     m0_net* nethandle_b = nullptr;
     Net* net = nullptr;
     Net* net_b = nullptr;                 // arena: the second network (games with an odd index play it as White)
+    Net* net_tail = nullptr;              // cfg.tail_split: a view of `net` (same weights, own stream + workspace) for the partial last round
+    hipStream_t stream_tail = nullptr;
+    hipEvent_t ev_sel = nullptr, ev_tail = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -451,11 +454,28 @@ int one_step(m0_selfplay* sp, std::string& err) {
     ForwardGate gate(sp->device, sp->stream, rows > 0 || sp->rows2[1] > 0);
     if (rows > 0) {
         if (!sp->net) { err = "m0_selfplay_step needs a network (use the split-step API without one)"; return M0_ERR_STATE; }
+        // tail split: the rows beyond the last whole round of workgroups (1024 boards = 256 four-board tiles) go to the second
+        // instance on its own stream, behind the select kernel and in front of the expand kernel by events; the main launches then
+        // have no partial last round and the tail's workgroups fill CUs as they come free
+        int main_rows = rows, tail_rows = 0;
+        if (sp->net_tail && rows >= 2048 && (rows & 1023) != 0) { main_rows = rows & ~1023; tail_rows = rows - main_rows; }
+        float* ssl = sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr;
         m0_net_lock(sp->nethandle);          // an infer_np on the same backend from another thread waits here
-        int rc = sp->net->forward(nullptr, sp->d.x0, rows, sp->logits_dev, sp->values_dev,
-                                  sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr, sp->stream, err);
+        int rc = M0_OK;
+        if (tail_rows > 0) (void)hipEventRecord(sp->ev_sel, sp->stream);          // the select kernel has written the batch
+        // main part first: its launches start at once, the tail's are enqueued while they run
+        rc = sp->net->forward(nullptr, sp->d.x0, main_rows, sp->logits_dev, sp->values_dev, ssl, sp->stream, err);
+        if (rc == M0_OK && tail_rows > 0) {
+            (void)hipStreamWaitEvent(sp->stream_tail, sp->ev_sel, 0);
+            const size_t sslw = ssl ? (size_t)sp->net->ssl_channels_total() * 64 : 0;
+            rc = sp->net_tail->forward(nullptr, sp->d.x0 + (size_t)main_rows * 64 * 32, tail_rows, sp->logits_dev + (size_t)main_rows * 4672,
+                                       sp->values_dev + main_rows, ssl ? ssl + (size_t)main_rows * sslw : nullptr, sp->stream_tail, err);
+            (void)hipEventRecord(sp->ev_tail, sp->stream_tail);
+            (void)hipStreamWaitEvent(sp->stream, sp->ev_tail, 0);
+        }
         m0_net_unlock(sp->nethandle);
         if (rc != M0_OK) return rc;
+        sp->stats.rows_tail += (uint64_t)tail_rows;
     }
     if (sp->rows2[1] > 0) {                 // arena: the other network's leaves, in their own region of the batch
         if (!sp->net_b) { err = "rows for a second network without one"; return M0_ERR_STATE; }
@@ -687,6 +707,18 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     sp->hsamples.resize((size_t)sp->G * (sp->L + 1));
     sp->prev_done.assign(sp->G, 0);
     (void)hipEventCreate(&sp->ev0); (void)hipEventCreate(&sp->ev1); (void)hipEventCreate(&sp->ev2); (void)hipEventCreate(&sp->ev3);
+    if (cfg->tail_split && sp->net && !sp->cfg.arena_mode && sp->net->cfg().channels > 256 && sp->net->cfg().channels <= 320 &&
+        sp->rows_max >= 2048) {
+        if (hipStreamCreateWithFlags(&sp->stream_tail, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&sp->ev_sel, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&sp->ev_tail, hipEventDisableTiming) == hipSuccess) {
+            sp->net_tail = sp->net->shared_view(sp->stream_tail);
+        } else {
+            m0_set_error("hipStreamCreate / hipEventCreate failed (tail split)");
+            m0_selfplay_destroy(sp);
+            return nullptr;
+        }
+    }
     if (sp->net) {
         std::string err;
         if (sp->net->ensure_workspace(sp->rows_max, err) != M0_OK) { m0_set_error(err); m0_selfplay_destroy(sp); return nullptr; }
@@ -720,6 +752,11 @@ void m0_selfplay_destroy(m0_selfplay* sp) {
     if (sp->counted) g_engines_with_net[sp->device].fetch_sub(1);
     (void)hipSetDevice(sp->device);
     if (sp->stream) (void)hipStreamSynchronize(sp->stream);
+    if (sp->stream_tail) (void)hipStreamSynchronize(sp->stream_tail);
+    delete sp->net_tail;
+    if (sp->ev_sel) (void)hipEventDestroy(sp->ev_sel);
+    if (sp->ev_tail) (void)hipEventDestroy(sp->ev_tail);
+    if (sp->stream_tail) (void)hipStreamDestroy(sp->stream_tail);
     for (void* p : sp->allocs) (void)hipFree(p);
     for (auto& r : sp->done_meta) delete (GameRecordOwner*)r.owner;
     if (sp->ev0) { (void)hipEventDestroy(sp->ev0); (void)hipEventDestroy(sp->ev1); (void)hipEventDestroy(sp->ev2); (void)hipEventDestroy(sp->ev3); }

@@ -342,3 +342,36 @@ def test_baseline_config0_one_game_64_sims_full_size_net():
     st = e.stats()
     assert 64 * T * 0.9 <= st["sims"] <= 64 * T * 1.1 + 64      # playout cap +-5 %
     np.testing.assert_allclose(g["pi"].sum(axis=1), 1.0, atol=1e-4)
+
+
+def test_tail_split_leaves_the_games_unchanged():
+    """engine.tail_split: a pass of >= 2048 rows on the 320-wide network = a whole number of workgroup rounds on the main instance + the
+    rest on a second instance over the same weights, concurrently.  The forward is bitwise batch invariant, so the games must be
+    the same, bit for bit, with the split on and off -- and the split must actually have been taken."""
+    from matrix0_amd.backend import M0Backend
+    from matrix0_amd import engine as eng
+    net = dict(planes=19, channels=320, blocks=3, attention_heads=20, policy_size=4672, norm="group", activation="silu",
+               preact=True, policy_factor_rank=128, self_supervised=True, ssl_tasks=["piece", "control"])
+    be = M0Backend.from_state_dict(net, net_ref.random_state_dict(net, seed=31))
+    cfgd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in CFG.items()}
+    cfgd["mcts"] = dict(cfgd["mcts"], inference_batch_size=96)
+    cfgd["selfplay"] = dict(cfgd["selfplay"], num_simulations=200, max_game_len=3, opening_random_plies=1)
+
+    def play(split, ssl):
+        e = eng.SelfplayEngine(be, eng.selfplay_cfg_from_dict(cfgd, concurrent_games=40, total_games=40, tail_split=split,
+                                                              ssl_in_forward=ssl))
+        games = _play_all(e)
+        st = e.stats()
+        e.close()
+        return games, st
+
+    for ssl in (False, True):
+        off, st_off = play(False, ssl)
+        on, st_on = play(True, ssl)
+        assert sorted(off) == sorted(on) == list(range(40))
+        for i in range(40):
+            assert off[i]["played"] == on[i]["played"], i
+            for k in ("pi", "z", "s", "legal_mask", "search_values"):
+                assert np.array_equal(off[i][k], on[i][k]), (i, k)
+        assert st_off["rows_tail"] == 0 and st_on["rows_tail"] > 0 and st_on["evals"] == st_off["evals"]
+    be.close()
