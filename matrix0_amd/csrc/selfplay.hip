@@ -713,6 +713,12 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
             hipEventCreateWithFlags(&sp->ev_sel, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&sp->ev_tail, hipEventDisableTiming) == hipSuccess) {
             sp->net_tail = sp->net->shared_view(sp->stream_tail);
+            std::string werr;                   // its workspace now, at its largest (a regrowth synchronises the device)
+            if (sp->net_tail->ensure_workspace(1023, werr) != M0_OK) {
+                m0_set_error("tail split: " + werr);
+                m0_selfplay_destroy(sp);
+                return nullptr;
+            }
         } else {
             m0_set_error("hipStreamCreate / hipEventCreate failed (tail split)");
             m0_selfplay_destroy(sp);
