@@ -332,7 +332,10 @@ __device__ __forceinline__ size_t tt_table_of(const TreeDev& d, int g, const Gam
 // copied once per launch; the children scan reads them from LDS instead of paying a global round trip per level, and the two
 // things a select launch writes to such nodes (in-flight counts, the statistics of a terminal leaf's path) are written through.
 // Deeper nodes -- and everything in the table modes, whose arenas are not compacted -- are read from the arenas in HBM as before.
-constexpr int M0_SEL_CACHE = 2048;
+#ifndef M0_SEL_CACHE_N
+#define M0_SEL_CACHE_N 2048
+#endif
+constexpr int M0_SEL_CACHE = M0_SEL_CACHE_N;
 constexpr int M0_SEL_CACHE_BYTES = M0_SEL_CACHE * 32;
 
 __global__ __launch_bounds__(64) void select_kernel(TreeDev d, TreeCfg c) {
