@@ -246,6 +246,17 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     if (wp == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier
     __builtin_amdgcn_s_barrier();                       // every wave's DMA has landed before anyone stages output (tools/ubench/conv_pp.hip)
 
+#ifdef ZS_PREFETCH
+    // L2 prefetch of the first activation chunk of the tile that the XCD's NEXT round of workgroups brings (workgroup ids go to the
+    // XCDs round-robin, so tile blockIdx.x + 256 k lands on this XCD): one 4-byte load per row = one per 128-byte line of the
+    // chunk, issued before the epilogue, retired (by the compiler's own wait) at the very end.
+    float zs_pf = 0.f;
+    {
+        const int nrow = m0 + 256 * ZS_PREFETCH + (tid & 255);
+        if (tid < 256 && nrow < a.Mrows)
+            zs_pf = *reinterpret_cast<const volatile float*>(in_bytes + (size_t)nrow * Cin * 2);
+    }
+#endif
 #ifdef PP_NO_EPILOGUE
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -255,6 +266,9 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     if constexpr (EPI == 3) zs_tail_epilogue<ACT, false>(acc, a, smem, m0, wp, wn, wave, lane);
     else if constexpr (EPI == 5) zs_tail_epilogue<ACT, true>(acc, a, smem, m0, wp, wn, wave, lane);
     else zs_tile_epilogue<EPI, ACT>(acc, a, smem + wave * 20480, m0, n0, wp, wn, lane);
+#endif
+#ifdef ZS_PREFETCH
+    asm volatile("" :: "v"(zs_pf));
 #endif
 #ifdef SW_STAMP     // timeline of the workgroup (10-ns ticks, wave 0) and where it ran: [blocks][4] behind the main-loop stamps
     if (tid == 0) {
