@@ -8,6 +8,10 @@
 #include "../../matrix0_amd/csrc/conv_pp16.hip"
 #include "../../matrix0_amd/csrc/conv_zs.hip"
 #include "conv_z2.hip"
+#include "conv_zd.hip"
+#ifdef BENCH_ZD
+#define launch_conv_pp launch_conv_zd
+#endif
 #ifdef BENCH_Z2
 #define launch_conv_pp launch_conv_z2
 #endif
@@ -21,6 +25,7 @@
 #define launch_conv_pp launch_conv_pp16
 #endif
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 #include <map>
@@ -102,6 +107,12 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_sw_stamp), &dst_, sizeof(dst_));
 #elif defined(BENCH_Z2)
     hipMemcpyToSymbol(HIP_SYMBOL(g_z2_stamp), &dst_, sizeof(dst_));
+#elif defined(BENCH_ZD)
+    hipMemcpyToSymbol(HIP_SYMBOL(g_zd_stamp), &dst_, sizeof(dst_));
+    {   // BENCH_CMPZD also launches conv_zs_kernel, whose stamps need a home of their own
+        unsigned long long* dzs; hipMalloc(&dzs, (size_t)(M / 256) * 16 * 8); hipMemset(dzs, 0, (size_t)(M / 256) * 16 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_zs_stamp), &dzs, sizeof(dzs));
+    }
 #elif defined(BENCH_ZS)
     hipMemcpyToSymbol(HIP_SYMBOL(g_zs_stamp), &dst_, sizeof(dst_));
 #elif defined(BENCH_P16)
@@ -119,6 +130,33 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_tail_stamp), &dtail_, sizeof(dtail_));
 #endif
     hipStream_t st; hipStreamCreate(&st);
+#ifdef BENCH_CMPZD   // conv_zd_kernel (square tiles of 16 boards, all padding skipped) against conv_zs_kernel: same sums in another order
+    {
+        const size_t nb = (size_t)M * C * 2;
+        std::vector<_Float16> o1((size_t)M * C), o2((size_t)M * C), o3((size_t)M * C);
+        hipMemset(dout, 0, nb);
+        hipError_t e1 = launch_conv_zs(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o1.data(), dout, nb, hipMemcpyDeviceToHost);
+        hipMemset(dout, 0xff, nb);
+        hipError_t e2 = launch_conv_zd(a, st); hipError_t e2s = hipStreamSynchronize(st);
+        hipMemcpy(o2.data(), dout, nb, hipMemcpyDeviceToHost);
+        hipMemset(dout, 0, nb);
+        launch_conv_zd(a, st); hipStreamSynchronize(st);
+        hipMemcpy(o3.data(), dout, nb, hipMemcpyDeviceToHost);
+        size_t bad = 0, rep = 0, nan = 0; double md = 0, mx = 0; size_t worst = 0;
+        for (size_t i = 0; i < o1.size(); ++i) {
+            const double d = fabs((double)o1[i] - (double)o2[i]);
+            if (!(d == d)) { ++nan; continue; }
+            if (d > 4e-3 * (1.0 + fabs((double)o1[i]))) ++bad;
+            if (d > md) { md = d; worst = i; }
+            if (fabs((double)o1[i]) > mx) mx = fabs((double)o1[i]);
+            if (memcmp(&o2[i], &o3[i], 2) != 0) ++rep;
+        }
+        printf("compare conv_zs (%s) vs conv_zd (%s / %s): %zu of %zu beyond 4e-3 rel, %zu NaN, max |d| %.3g at row %zu col %zu (|out| max %.3g); repeat launch: %zu differing; out[0..3] = %g %g %g %g | %g %g %g %g\n",
+               hipGetErrorString(e1), hipGetErrorString(e2), hipGetErrorString(e2s), bad, o1.size(), nan, md, worst / C, worst % C, mx, rep,
+               (double)o1[0], (double)o1[1], (double)o1[2], (double)o1[3], (double)o2[0], (double)o2[1], (double)o2[2], (double)o2[3]);
+    }
+#endif
 #ifdef BENCH_CMPZ2   // conv_z2_kernel (2 workgroups per CU) against conv_zs_kernel on the same operands: bit for bit
     {
         const size_t nb = (size_t)M * C * 2;
@@ -172,7 +210,7 @@ int main(int argc, char** argv) {
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, fl = 2.0 * M * C * C * 9.0;
     printf("conv_pp boards=%d: %.1f us/launch, %.1f TFLOP/s  (%s)\n", boards, us, fl / us / 1e6, hipGetErrorString(hipGetLastError()));
-#ifdef SW_STAMP
+#if defined(SW_STAMP) && !defined(BENCH_ZD)
     {
         std::vector<unsigned long long> hs((size_t)(M / 256) * 4);
         hipMemcpy(hs.data(), dst_, hs.size() * 8, hipMemcpyDeviceToHost);
@@ -242,6 +280,22 @@ int main(int argc, char** argv) {
         printf("  per CU: tiles min %.0f median %.0f max %.0f; busy us min %.1f median %.1f max %.1f; first entry after launch start: median %.1f max %.1f us; idle at the end: median %.1f max %.1f us\n",
                cnt.front(), cnt[cnt.size() / 2], cnt.back(), busy.front(), busy[busy.size() / 2], busy.back(), first[first.size() / 2], first.back(),
                last[last.size() / 2], last.back());
+    }
+#endif
+#if defined(SW_STAMP) && defined(BENCH_ZD)
+    {   // conv_zd_kernel: per workgroup entry / loop start / loop end / exit (10-ns ticks) and loop cycles
+        const int nwg = ((boards + 15) / 16 + 7) / 8 * 32;
+        std::vector<unsigned long long> hs((size_t)nwg * 8);
+        hipMemcpy(hs.data(), dst_, hs.size() * 8, hipMemcpyDeviceToHost);
+        double pro = 0, loop = 0, epi = 0; std::vector<double> cyc; int n = 0;
+        for (int b = 0; b < nwg; ++b) {
+            if (hs[b * 8 + 3] == 0) continue;
+            pro += (double)(hs[b * 8 + 1] - hs[b * 8 + 0]); loop += (double)(hs[b * 8 + 2] - hs[b * 8 + 1]); epi += (double)(hs[b * 8 + 3] - hs[b * 8 + 2]);
+            cyc.push_back((double)hs[b * 8 + 4]); ++n;
+        }
+        std::sort(cyc.begin(), cyc.end());
+        if (n) printf("conv_zd per workgroup (n=%d): prologue %.2f us, main loop %.2f us (median %.0f cycles -> %.0f MHz), epilogue %.2f us\n",
+                      n, pro / n * 0.01, loop / n * 0.01, cyc[cyc.size() / 2], cyc[cyc.size() / 2] / (loop / n * 0.01), epi / n * 0.01);
     }
 #endif
 #if defined(SW_STAMP) && defined(BENCH_P16)
