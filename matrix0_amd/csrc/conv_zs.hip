@@ -150,7 +150,11 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
         }
         const bool more = t_next + 1 < NH;
         const size_t inc = (t_next & 1) ? (w_kt_stride - ZS_WH_BYTES) : (size_t)ZS_WH_BYTES;   // odd -> even: next K-tile
+#ifndef ZS_W_SAME      // timing experiment: every half-tile re-reads the same 20 KB of weights (L1 / L2 hits; results wrong)
         w_ptr += more ? inc : 0;
+#else
+        (void)more; (void)inc;
+#endif
         t_next += 1;
         w_slot = (t_next & 3) * ZS_WH_BYTES;
     };
