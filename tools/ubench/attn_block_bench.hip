@@ -4,6 +4,9 @@
 // The first 4 boards are compared with a plain fp32 CPU computation of the block (qkv and O rounded to fp16 where the
 // kernel rounds them); then the launch is timed.
 #include "../../matrix0_amd/csrc/attn_block.hip"
+#ifdef AB_AFTER_CONV   // every attention launch behind six conv_zs launches, as in the tower (is its in-network time the convs' clock?)
+#include "../../matrix0_amd/csrc/conv_zs.hip"
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -200,6 +203,35 @@ int main(int argc, char** argv) {
             fclose(f);
         }
     }
+#ifdef AB_AFTER_CONV
+    {
+        std::vector<_Float16> hw((size_t)9 * C * C);
+        for (auto& v : hw) v = (_Float16)(rnd() * 0.05f);
+        _Float16 *dcw, *dt; hipMalloc(&dcw, hw.size() * 2); hipMalloc(&dt, M * C * 2);
+        hipMemcpy(dcw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        GemmArgs g{};
+        g.in = dx; g.w = dcw; g.out = dt; g.Mrows = (int)M; g.Mvalid = (int)M; g.Cin = C; g.N = C; g.Npad = C; g.ldo = C; g.out_scale = 1.f; g.w_pp = 1;
+        g.gn_gamma = dg2; g.gn_beta = db2; g.epi_act = ACT_SILU;
+        const int nit = iters < 40 ? iters : 40;
+        std::vector<hipEvent_t> ev(2 * nit + 2);
+        for (auto& e_ : ev) hipEventCreate(&e_);
+        for (int w = 0; w < 2; ++w) { for (int k = 0; k < 6; ++k) launch_conv_zs(g, st); launch_attn_block(a, st); }
+        hipEventRecord(ev[2 * nit], st);
+        for (int i = 0; i < nit; ++i) {
+            for (int k = 0; k < 6; ++k) launch_conv_zs(g, st);
+            hipEventRecord(ev[2 * i], st);
+            launch_attn_block(a, st);
+            hipEventRecord(ev[2 * i + 1], st);
+        }
+        hipEventRecord(ev[2 * nit + 1], st);
+        hipStreamSynchronize(st);
+        double tot = 0, mn = 1e9, mx = 0; float all = 0.f;
+        for (int i = 0; i < nit; ++i) { float m_ = 0.f; hipEventElapsedTime(&m_, ev[2 * i], ev[2 * i + 1]); tot += m_; mn = m_ < mn ? m_ : mn; mx = m_ > mx ? m_ : mx; }
+        hipEventElapsedTime(&all, ev[2 * nit], ev[2 * nit + 1]);
+        printf("behind six conv_zs launches each (%d rounds, %s): attn_block %.1f us / launch (min %.1f max %.1f); six convs %.1f us each\n", nit,
+               hipGetErrorString(hipGetLastError()), tot / nit * 1e3, mn * 1e3, mx * 1e3, (all - tot) / nit / 6.0 * 1e3);
+    }
+#endif
     for (int i = 0; i < 3; ++i) launch_attn_block(a, st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, st);
