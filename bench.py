@@ -203,6 +203,11 @@ def main():
                     help="engine.tail_split: evaluate a pass as a whole number of workgroup rounds + a concurrent tail on a second "
                          "instance over the same weights (bit-identical games; +0.4..0.5 %% measured, and the event-bracketed conv "
                          "times then include the tail's workgroups, so the default bench keeps one forward per pass)")
+    ap.add_argument("--half-split", action="store_true",
+                    help="engine.tail_split = 'halves': a pass as two half batches on two instances over the same weights, side by side "
+                         "(bit-identical games; +1.3 %% measured: one half's attention blocks run beside the other half's convs).  The "
+                         "halves' kernels overlap, so the event-bracketed conv times -- and `roofline` -- no longer describe one kernel "
+                         "on the whole chip; the default bench keeps one forward per pass")
     ap.add_argument("--cu-split", action="store_true",
                     help="experiment (with --streams 2): the two engines' streams run on complementary CU halves of every XCD")
     args = ap.parse_args()
@@ -272,7 +277,7 @@ def main():
         """One engine, warm-up, then the timed region of exactly `--steps` searched plies per resident game."""
         kw = dict(concurrent_games=args.games, total_games=0, first_game_index=first_index, leaves_per_step=args.leaves,
                   virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache,
-                  tail_split=args.tail_split)
+                  tail_split=("halves" if args.half_split else args.tail_split))
         if args.streams > 1:
             made = [be]
             e = eng.SelfplayPool(lambda: made.pop() if made else make_backend(),
@@ -376,7 +381,8 @@ def main():
             # second instance over the same weights, at the same time (results unchanged: the forward is bitwise batch invariant).
             # `roofline` is taken from the main instance's launches (their FLOP over their event time); the tail's convs run inside
             # those windows on CUs the main launches would have left idle.
-            "tail_split": {"on": bool(args.tail_split), "share_of_evaluations": rows_tail / max(1.0, evals)},
+            "tail_split": {"on": bool(args.tail_split or args.half_split), "mode": "halves" if args.half_split else ("tail" if args.tail_split else "off"),
+                           "share_of_evaluations": rows_tail / max(1.0, evals)},
             # second timed region of the same K plies with the product default engine.eval_cache on (module docstring)
             "eval_cache": (None if second is None and not primary_cache else (
                 {"in_value": True, "evaluations_from_cache": int(cached), "share_of_leaf_evaluations": cached / max(1.0, cached + evals)}

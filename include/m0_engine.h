@@ -202,7 +202,10 @@ typedef struct m0_selfplay_cfg {
     /* 1 = a pass of >= 2048 rows on the 320-wide network is evaluated as a main part that is a whole number of rounds of
      * workgroups (a multiple of 1024 boards) plus a tail (< 1024 boards) on a second instance over the same weights, on its own
      * stream, at the same time: the tower is board-local, and the tail's workgroups run on the CUs the main launches' partial last
-     * round would leave idle.  Results are unchanged (the forward is bitwise batch invariant).  Self-play engines only. */
+     * round would leave idle.  Results are unchanged (the forward is bitwise batch invariant).  Self-play engines only.
+     * 2 = a pass of >= 4096 rows as two halves (the first a multiple of 1024 boards) on the two instances side by side: one
+     * half's attention blocks then run beside the other half's power-bound convs instead of behind them (+1.3 % games/s
+     * measured); per-launch kernel timings of the two halves overlap.  0 = off (default). */
     int tail_split;
 } m0_selfplay_cfg;
 

@@ -556,6 +556,11 @@ hipError_t launch_ew_board(const EwArgs& a, int boards, hipStream_t st) {
 // threads.  The gate is a chain of dependent global-memory latencies, so it runs here, once, with every weight
 // fetched in batches of 16 independent loads and used for 8 boards, instead of inside each board's ew_board
 // workgroup (measured there: +100 us per call).
+// The multiply-adds are explicit fused operations.  Written as `s[q] += w * x` over the 8 boards of a thread, hipcc fused some
+// of the eight and compiled the others as a packed multiply followed by a packed add (two roundings): the gate of a board then
+// depended, in the last bit, on its position in the batch modulo 8 -- found in round 4 as root values that differed by 1e-6
+// from run to run whenever two games raced for batch rows (tools/race_screen_small.py), and as a self-play test that failed
+// once in a few dozen runs.  (The 320-wide path has its own squeeze-excite in conv_zs_tail.h and was never affected.)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(384) void se_gate_kernel(SeGateArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(384) void se_gate_kernel(SeGateArgs a) {
                 for (int u = 0; u < 16; ++u) {
                     const int c = cb + u < cend ? cb + u : cbeg;      // w[u] == 0 past the end
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) s[q] += w[u] * pool[q * C + c];
+                    for (int q = 0; q < 8; ++q) s[q] = __builtin_fmaf(w[u], pool[q * C + c], s[q]);   // explicit: see the header
                 }
             }
 #pragma unroll
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(384) void se_gate_kernel(SeGateArgs a) {
             for (int u = 0; u < 16; ++u) {
                 const int j = jb + u < Hd ? jb + u : 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s[q] += w[u] * hid[q * Hd + j];
+                for (int q = 0; q < 8; ++q) s[q] = __builtin_fmaf(w[u], hid[q * Hd + j], s[q]);
             }
         }
         for (int q = 0; q < nb; ++q) a.gate[(size_t)(b0 + q) * C + c] = 1.f / (1.f + __expf(-s[q]));

@@ -68,6 +68,7 @@ struct m0_selfplay {
     Net* net_tail = nullptr;              // cfg.tail_split: a view of `net` (same weights, own stream + workspace) for the partial last round
     hipStream_t stream_tail = nullptr;
     hipEvent_t ev_sel = nullptr, ev_tail = nullptr;
+    bool half_split = false;              // cfg.tail_split == 2: two halves instead of main + tail
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -459,6 +460,10 @@ int one_step(m0_selfplay* sp, std::string& err) {
         // have no partial last round and the tail's workgroups fill CUs as they come free
         int main_rows = rows, tail_rows = 0;
         if (sp->net_tail && rows >= 2048 && (rows & 1023) != 0) { main_rows = rows & ~1023; tail_rows = rows - main_rows; }
+        // tail_split = 2: the pass as two halves (the first one a whole number of rounds) on the two streams.  Two forwards side by
+        // side keep the chip's power draw even -- one half's attention blocks (latency-bound, low power) fall beside the other
+        // half's convs (power-bound) instead of running behind them at the clock they leave: +1.3 % games/s
+        if (sp->net_tail && sp->half_split && rows >= 4096) { main_rows = ((rows / 2) + 1023) & ~1023; tail_rows = rows - main_rows; }
         float* ssl = sp->cfg.ssl_in_forward ? sp->ssl_dev : nullptr;
         m0_net_lock(sp->nethandle);          // an infer_np on the same backend from another thread waits here
         int rc = M0_OK;
@@ -714,7 +719,8 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
             hipEventCreateWithFlags(&sp->ev_tail, hipEventDisableTiming) == hipSuccess) {
             sp->net_tail = sp->net->shared_view(sp->stream_tail);
             std::string werr;                   // its workspace now, at its largest (a regrowth synchronises the device)
-            if (sp->net_tail->ensure_workspace(1023, werr) != M0_OK) {
+            sp->half_split = cfg->tail_split == 2;
+            if (sp->net_tail->ensure_workspace(sp->half_split ? sp->rows_max / 2 + 1024 : 1023, werr) != M0_OK) {
                 m0_set_error("tail split: " + werr);
                 m0_selfplay_destroy(sp);
                 return nullptr;

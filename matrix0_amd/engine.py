@@ -108,7 +108,7 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
                            virtual_loss_active: bool = True, ssl_in_forward: bool = False,
                            record_games: bool = True, arena_nodes: int = 0, ssl_targets: bool = False,
                            compat: Optional[dict] = None, eval_cache: Optional[bool] = None,
-                           tail_split: Optional[bool] = None) -> SelfplayCfg:
+                           tail_split=None) -> SelfplayCfg:
     """Merge config.yaml's `mcts`, `selfplay` and draw sections exactly as selfplay_worker does
     (azchess/selfplay/internal.py:192-199, 269-304) into the engine's C struct.  MCTSConfig
     defaults are the dataclass defaults of azchess/mcts.py:61-107."""
@@ -190,9 +190,11 @@ def selfplay_cfg_from_dict(cfg: dict, *, concurrent_games: int, total_games: int
     ecfg = cfg.get("engine", {}) or {}
     c.eval_cache = int(bool(ecfg.get("eval_cache", False) if eval_cache is None else eval_cache))
     c.eval_cache_entries = int(ecfg.get("eval_cache_entries", 0) or 0)
-    # `engine.tail_split` (default off: +0.4..0.5 % games/s measured): the partial last round of a big pass runs on
-    # a second instance over the same weights beside the main forward
-    c.tail_split = int(bool(ecfg.get("tail_split", False) if tail_split is None else tail_split))
+    # `engine.tail_split` (default off): true / 1 = the partial last round of a big pass runs on a second instance
+    # over the same weights beside the main forward (+0.4..0.5 % games/s measured); "halves" / 2 = the pass as two halves side by
+    # side (+1.3 %; the halves' kernel timings overlap)
+    ts = ecfg.get("tail_split", False) if tail_split is None else tail_split
+    c.tail_split = 2 if ts in ("halves", "half", 2) and ts is not True else int(bool(ts))
     return c
 
 

@@ -103,3 +103,16 @@ def test_config_mapping_matches_reference_yaml_semantics():
     assert c.dirichlet_plies == 30 and c.legal_softmax == 1 and c.inference_batch_size == 96
     assert c.draw_enabled == 0 and c.draw_halfmove_cap == 100 and c.seed == 7
     assert c.resign_consecutive_bad == 5 and c.resign_window == 4
+
+
+def test_engine_section_switches_map_to_the_cabi_fields():
+    """`engine.eval_cache` / `engine.tail_split` of config.yaml (engine-only switches, off unless asked for) -> m0_selfplay_cfg."""
+    base = eng.selfplay_cfg_from_dict({}, concurrent_games=4)
+    assert base.eval_cache == 0 and base.tail_split == 0
+    for given, want in ((False, 0), (True, 1), (1, 1), (2, 2), ("halves", 2), (0, 0)):
+        assert eng.selfplay_cfg_from_dict({}, concurrent_games=4, tail_split=given).tail_split == want, given
+        assert eng.selfplay_cfg_from_dict({"engine": {"tail_split": given}}, concurrent_games=4).tail_split == want, given
+    # the keyword wins over the config section
+    assert eng.selfplay_cfg_from_dict({"engine": {"tail_split": "halves", "eval_cache": True}}, concurrent_games=4,
+                                      tail_split=False, eval_cache=False).tail_split == 0
+    assert eng.selfplay_cfg_from_dict({"engine": {"eval_cache": True}}, concurrent_games=4).eval_cache == 1

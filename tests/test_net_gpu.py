@@ -329,6 +329,37 @@ def test_full_size_batch_invariance_and_determinism():
     assert start == B
 
 
+@pytest.mark.parametrize("kw", [{}, {"channels": 64, "attention_heads": 4}, {"blocks": 3}, {"se": False}],
+                         ids=["32ch", "64ch", "3blocks_attention", "no_se"])
+def test_narrow_networks_do_not_depend_on_the_position_in_the_batch(kw):
+    """The narrow-trunk path (small-tile convs, `se_gate_kernel`, `attn_core_kernel`, `ew_board_kernel`: every network that is not
+    320 wide, i.e. every small test network): a board's logits and value must be the same bits wherever it sits in a batch and
+    whatever else is in it.  Round 4: `se_gate_kernel` handled 8 boards per thread and hipcc fused the multiply-adds of some of
+    the eight only -- the gate depended on the position modulo 8 in the last bit, root values of concurrent games differed from run
+    to run (the games race for batch rows), and once in a few dozen runs a move flipped."""
+    from matrix0_amd.backend import M0Backend
+    cfg = dict(planes=19, channels=32, blocks=2, attention_heads=2, policy_size=4672, norm="group", activation="silu",
+               preact=True, policy_factor_rank=16, self_supervised=False)
+    cfg.update(kw)
+    be = M0Backend.from_state_dict(cfg, net_ref.random_state_dict(cfg, seed=1))
+    rng = np.random.default_rng(3)
+    B = 290                                                  # two 256-row FC tiles, a partial 4-board tile, a partial group of 8
+    x = np.zeros((B, 19, 8, 8), np.float32)
+    x[:, :12] = (rng.random((B, 12, 8, 8)) < 0.08).astype(np.float32)
+    x[:, 12:17] = (rng.random((B, 5, 1, 1)) < 0.5).astype(np.float32)
+    x[:, 17:] = rng.random((B, 2, 1, 1)).astype(np.float32)
+    p0, v0 = be.infer_np(x)
+    for i in (0, 5, 6, 7, 255, 256, 289):                    # alone in a batch of one
+        p, v = be.infer_np(x[i:i + 1])
+        assert np.array_equal(p[0], p0[i]) and v[0] == v0[i], i
+    for perm in (np.arange(B)[::-1], np.roll(np.arange(B), 1), np.roll(np.arange(B), 6), rng.permutation(B)):
+        p, v = be.infer_np(x[perm])
+        assert np.array_equal(p, p0[perm]) and np.array_equal(v, v0[perm])
+    p, v = be.infer_np(x[:143])
+    assert np.array_equal(p, p0[:143]) and np.array_equal(v, v0[:143])
+    be.close()
+
+
 def test_bench_size_forward_is_batch_invariant():
     """The forward of a self-play pass at the bench configuration takes 256 games x 96 leaves (+ 256 re-evaluated roots): 24 832
     boards in one launch sequence, 24 rounds of workgroups per CU in the conv kernels.  Boards 0..63, the last 61 boards and five 70-board

@@ -2,7 +2,7 @@
 """Race screen of the tree kernels + the self-play step: the same generation (64 games, R24-320 x 3 blocks, 400 simulations per move,
 96 leaves per pass, terminal positions reachable: KQK / KRK openings mixed in) is played N times; every run must reproduce the first
 one bit for bit (moves, visit distributions, values).  For new synchronisation in select / expand / advance (round 4: the
-LDS-resident top of the tree, written through from two places): `python tools/race_screen_search.py 8 [--tail-split]`."""
+LDS-resident top of the tree, written through from two places): `python tools/race_screen_search.py 8 [--tail-split | --half-split]`."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -11,7 +11,7 @@ from matrix0_amd.weights import random_state_dict
 from matrix0_amd import engine as eng
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6
-tail = "--tail-split" in sys.argv
+tail = "halves" if "--half-split" in sys.argv else ("--tail-split" in sys.argv)
 net = dict(planes=19, channels=320, blocks=3, attention_heads=20, policy_size=4672, norm="group", activation="silu",
            preact=True, policy_factor_rank=128, self_supervised=False)
 be = M0Backend.from_state_dict(net, random_state_dict(net, seed=5, varied=True))
