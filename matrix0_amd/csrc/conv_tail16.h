@@ -110,7 +110,7 @@ __device__ __forceinline__ void conv_tail_epilogue16(float4v (&acc)[4][10], cons
                 for (int c = cbeg; c < cend; ++c) {
                     const float w = (float)w1l[c * Hd + j];
                     const float4 pv = *reinterpret_cast<const float4*>(pool + c * 4);
-                    s0 += w * pv.x; s1 += w * pv.y; s2 += w * pv.z; s3 += w * pv.w;
+                    s0 = __builtin_fmaf(w, pv.x, s0); s1 = __builtin_fmaf(w, pv.y, s1); s2 = __builtin_fmaf(w, pv.z, s2); s3 = __builtin_fmaf(w, pv.w, s3);   // explicit: all four boards alike (se_gate_kernel's header)
                 }
                 float* pp = part + (p * 4) * 128 + j;
                 pp[0] = s0; pp[128] = s1; pp[256] = s2; pp[384] = s3;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void conv_tail_epilogue16(float4v (&acc)[4][10], cons
             for (int j = 0; j < Hd; ++j) {
                 const float w = (float)w2l[j * C + tid];
                 const float4 hv = *reinterpret_cast<const float4*>(hid + j * 4);
-                s0 += w * hv.x; s1 += w * hv.y; s2 += w * hv.z; s3 += w * hv.w;
+                s0 = __builtin_fmaf(w, hv.x, s0); s1 = __builtin_fmaf(w, hv.y, s1); s2 = __builtin_fmaf(w, hv.z, s2); s3 = __builtin_fmaf(w, hv.w, s3);
             }
             gate[tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s0));
             gate[C + tid] = __builtin_amdgcn_rcpf(1.f + __expf(-s1));

@@ -179,6 +179,17 @@ def test_conv_kernel_variants_agree(monkeypatch):
         p_ref, v_ref = net_ref.forward(sd, cfg, x, return_ssl=False)[:2]
         for tag, p, v in (("pp16", p16, v16), ("zs", pzs, vzs)):
             _check(f"conv_{tag}:{sorted(extra.items())}", p, v, p_ref.numpy(), v_ref.numpy())
+        # both kernels' tails handle the four boards of a tile in one thread: a board's result must not depend on which of the
+        # four it is (the squeeze-excite sums are explicit fused multiply-adds for that reason, round 4) -- rotate the batch
+        perm = np.roll(np.arange(B), 1)
+        monkeypatch.setenv("M0_CONV_ZS", "0")
+        be16 = M0Backend.from_state_dict(cfg, sd)
+        monkeypatch.delenv("M0_CONV_ZS")
+        pr, vr = be16.infer_np(x.numpy()[perm])
+        be16.close()
+        assert np.array_equal(pr, p16[perm]) and np.array_equal(vr, v16[perm]), extra
+        pr, vr = be.infer_np(x.numpy()[perm])
+        assert np.array_equal(pr, pzs[perm]) and np.array_equal(vr, vzs[perm]), extra
 
 
 def test_fused_attention_block_matches_split_kernels(monkeypatch):
