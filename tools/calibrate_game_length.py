@@ -13,10 +13,11 @@ import bench
 
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 leaves = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1000.0
+budget = float(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 1000.0
+split = "halves" if "--half-split" in sys.argv else False       # engine.tail_split (the games are the same either way)
 be = M0Backend.from_state_dict(bench.R24_320, random_state_dict(bench.R24_320, seed=0, varied=True))
 cfg = eng.selfplay_cfg_from_dict(bench.SELFPLAY_CFG, concurrent_games=games, total_games=games, leaves_per_step=leaves,
-                                 virtual_loss_active=True, record_games=True, eval_cache=True)
+                                 virtual_loss_active=True, record_games=True, eval_cache=True, tail_split=split)
 e = eng.SelfplayEngine(be, cfg)
 t0 = time.time(); recs = []; last = t0
 while e.running() and time.time() - t0 < budget:
@@ -45,5 +46,6 @@ out = {"games": len(recs), "games_requested": games, "complete": len(recs) == ga
        "note": "searched plies per game (NPZ rows); opening_random_plies=12 not included; R24-320 random init, 800 sims/move, "
                f"{games} concurrent games, {leaves} leaves/tree/step"}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "game_length.json"), "w"), indent=1)
+out["tail_split"] = split or "off"
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "game_length_halves.json" if split else "game_length.json"), "w"), indent=1)
 print(json.dumps(out))
