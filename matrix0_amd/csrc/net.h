@@ -147,7 +147,6 @@ private:
     float *SX_ = nullptr, *S1_ = nullptr, *S2_ = nullptr, *G_ = nullptr;   // G_: squeeze-excite gates [B][C]
     _Float16 *PH_ = nullptr, *PH2_ = nullptr, *VH_ = nullptr, *VH2_ = nullptr, *F1_ = nullptr, *F2_ = nullptr,
              *F3_ = nullptr, *F4_ = nullptr, *SH_ = nullptr, *SH2_ = nullptr, *SO_ = nullptr;
-    float* LOG_ = nullptr;
     float* VAL_ = nullptr;
 
     const HostTensor* get(const std::string& k, std::string& err);

@@ -656,7 +656,7 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
         float mx = -3.0e38f;
         int cnt;                                      // size of the active distribution
         double ent = 0.0;
-        double fsum = 1.0, fmx = 0.0;                 // full-softmax normaliser (legal_softmax == 0)
+        double fsum = 1.0;                            // full-softmax normaliser (legal_softmax == 0)
         if (c.legal_softmax) {
             cnt = n;
             float l[4];
@@ -685,7 +685,7 @@ __device__ bool expand_node(const Arena& A, int cap, GameDev* gd, const TreeCfg&
             double sum = 0.0;
             for (int j = lane; j < 4672; j += 64) sum += exp((double)(lg[j] - mx));
             sum = wave_sum_d(sum);
-            fsum = sum; fmx = (double)mx;
+            fsum = sum;
             for (int j = lane; j < 4672; j += 64) {
                 const double pj = (double)(float)(exp((double)(lg[j] - mx)) / sum);
                 ent -= pj * log(pj + 1e-8);
