@@ -19,6 +19,8 @@ python bench.py --sims 1600 --steps 10 --no-cpu-baseline > $OUT/$TAG.bench_sims1
 echo "[profile] bench --sims 1600 done (BASELINE configs[4] search shape on one GPU)"
 python bench.py --streams 2 --no-cpu-baseline > $OUT/$TAG.bench_streams2.json 2> $OUT/$TAG.bench_streams2.err || exit 1
 echo "[profile] bench --streams 2 done"
+python bench.py --half-split --no-cpu-baseline > $OUT/$TAG.bench_half_split.json 2> $OUT/$TAG.bench_half_split.err || exit 1
+echo "[profile] bench --half-split done (engine.tail_split = halves; roofline fields not meaningful in this mode)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval-cache > $OUT/$TAG.bench_prof.json 2> $OUT/$TAG.stats.err || exit 1
 echo "[profile] kernel stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG.netstats -- python3 tools/bench_net.py $B > $OUT/$TAG.netstats.log 2>&1 || exit 1
