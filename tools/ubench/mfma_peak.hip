@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void mfma_loop(const _Float16* in, float* out,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-int main() {
+int main(int argc, char** argv) {
     _Float16* in; float* out;
     const int n = 65536;
     hipMalloc(&in, n * 2); hipMalloc(&out, 256 * 512 * 4 * 4);
@@ -32,6 +32,16 @@ int main() {
     for (int i = 0; i < n; ++i) h[i] = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
     hipMemcpy(in, h, n * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 1) {     // long run for tools/power_probe.sh: `mfma_peak <launches>` back to back, 2 waves per SIMD
+        const int reps = atoi(argv[1]), iters = 20000;
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_loop<10>, dim3(256), dim3(512), 0, 0, in, out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double flop = (double)reps * 256.0 * 8 * iters * 10.0 * 2.0 * 32 * 32 * 16;
+        printf("%d launches back to back, 2 waves/SIMD: %.1f ms, %.1f TFLOP/s sustained\n", reps, ms, flop / ms / 1e9);
+        return 0;
+    }
     for (int threads : {256, 512}) {
         for (int rep = 0; rep < 3; ++rep) {
             const int iters = 20000;
