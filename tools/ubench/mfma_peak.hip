@@ -23,6 +23,25 @@ __global__ __launch_bounds__(512) void mfma_loop(const _Float16* in, float* out,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the conv kernels' instruction: v_mfma_f32_16x16x32_f16, 40 independent accumulators per wave (8 x 5 tiles), same operand reuse
+typedef float float4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mfma_loop16(const _Float16* in, float* out, int iters) {
+    half8 a[8], b[5];
+    for (int i = 0; i < 8; ++i) a[i] = *(const half8*)(in + i * 4096 + threadIdx.x * 8);
+    for (int i = 0; i < 5; ++i) b[i] = *(const half8*)(in + 32768 + i * 4096 + threadIdx.x * 8);
+    float4m acc[8][5];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 5; ++j) acc[i][j] = float4m{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 5; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main(int argc, char** argv) {
     _Float16* in; float* out;
     const int n = 65536;
@@ -40,6 +59,15 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double flop = (double)reps * 256.0 * 8 * iters * 10.0 * 2.0 * 32 * 32 * 16;
         printf("%d launches back to back, 2 waves/SIMD: %.1f ms, %.1f TFLOP/s sustained\n", reps, ms, flop / ms / 1e9);
+        if (argc > 2) {   // `mfma_peak <launches> 16`: then the same with the conv kernels' 16x16x32 instruction (40 accumulators)
+            const int it16 = 10000;
+            hipEventRecord(e0);
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_loop16, dim3(256), dim3(512), 0, 0, in, out, it16);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            flop = (double)reps * 256.0 * 8 * it16 * 40.0 * 2.0 * 16 * 16 * 32;
+            printf("%d launches back to back, 16x16x32, 2 waves/SIMD: %.1f ms, %.1f TFLOP/s sustained (%s)\n", reps, ms, flop / ms / 1e9, hipGetErrorString(hipGetLastError()));
+        }
         return 0;
     }
     for (int threads : {256, 512}) {
