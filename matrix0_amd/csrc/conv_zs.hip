@@ -136,11 +136,27 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
     auto issue_next = [&](auto G_) __attribute__((always_inline)) {
         constexpr int G = decltype(G_)::value;
         char* dst = W_lds + w_slot + wave * 1024;
+#ifdef ZS_EMU8          // timing experiment: the DMA volume of an 8-board x 160-channel tile (half the weight pieces, twice the activation
+                        // pieces): group 0 two weight pieces, group 1 its activation piece (+ one weight piece with ZS_EMU8 = 2); results wrong
+        if constexpr (G == 0) { zs_glds16(w_ptr + w_lane, dst); zs_glds16(w_ptr + 8192 + w_lane, dst + 8192); }
+        else if (ZS_EMU8 == 2) zs_glds16(w_ptr + w_lane, dst);
+#else
         zs_glds16(w_ptr + w_lane, dst);
         zs_glds16(w_ptr + 8192 + w_lane, dst + 8192);
+#endif
+#if defined(ZS_SKIP_DMA) || defined(ZS_EMU8)      // timing experiments: fewer DMA pieces per wave and half-tile (results wrong)
+        if constexpr (G == 2) {
+#else
         if constexpr (G == 0) {
+#endif
             zs_glds16(w_ptr + 16384 + w_lane, dst + 16384);
+#if defined(ZS_SKIP_DMA)
+        } else if constexpr (G == 3) {
+#elif defined(ZS_EMU8)
+        } else if constexpr (G == 1) {
+#else
         } else {
+#endif
             const bool have = a_left > 0;
             const uint32_t al = ((8 - a_left) & 2) ? a_lane1 : a_lane0;     // pieces 2, 3, 6, 7 of this wave: odd boards
             zs_glds16_act((have ? a_ptr : in_bytes) + al, have ? A_lds + a_dst : D_lds + (wave - 4) * 1024);
@@ -211,7 +227,14 @@ __global__ __launch_bounds__(512) void conv_zs_kernel(GemmArgs a) {
                     // half-tile before this one) was read into registers by both wave groups at least a phase ago.
                     ZS_FENCE(); issue_next(G_); ZS_FENCE();
                     // all but this wave's three youngest pieces (the ones just issued) have landed
+#if defined(ZS_EMU8)
+                    if constexpr (G == 0 || ZS_EMU8 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#elif defined(ZS_SKIP_DMA)
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#else
                     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
                     ZS_FENCE();
                     __builtin_amdgcn_s_barrier();
                     ZS_FENCE();
