@@ -714,7 +714,23 @@ static m0_selfplay* selfplay_create_impl(m0_net* nh, m0_net* nh_b, const m0_self
     (void)hipEventCreate(&sp->ev0); (void)hipEventCreate(&sp->ev1); (void)hipEventCreate(&sp->ev2); (void)hipEventCreate(&sp->ev3);
     if (cfg->tail_split && sp->net && !sp->cfg.arena_mode && sp->net->cfg().channels > 256 && sp->net->cfg().channels <= 320 &&
         sp->rows_max >= 2048) {
-        if (hipStreamCreateWithFlags(&sp->stream_tail, hipStreamNonBlocking) == hipSuccess &&
+        // M0_TAIL_CU_MASK=w0,...,w7 (measurement switch, like M0_NET_CU_MASK for the network's own stream): the second instance's
+        // stream runs on those CUs only -- with complementary masks every launch of the two halves has a known share of the chip
+        hipError_t tse;
+        if (const char* mk = getenv("M0_TAIL_CU_MASK"); mk && *mk) {
+            uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int nw = 0;
+            for (const char* q = mk; *q && nw < 8; ++nw) {
+                char* end = nullptr;
+                words[nw] = (uint32_t)strtoul(q, &end, 16);
+                if (end == q) break;
+                q = (*end == ',') ? end + 1 : end;
+            }
+            tse = hipExtStreamCreateWithCUMask(&sp->stream_tail, 8, words);
+        } else {
+            tse = hipStreamCreateWithFlags(&sp->stream_tail, hipStreamNonBlocking);
+        }
+        if (tse == hipSuccess &&
             hipEventCreateWithFlags(&sp->ev_sel, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&sp->ev_tail, hipEventDisableTiming) == hipSuccess) {
             sp->net_tail = sp->net->shared_view(sp->stream_tail);
