@@ -27,6 +27,8 @@ cache on -- a leaf reached more than once in a pass shares one batch row and a p
 earlier passes, ~5 % of the leaf evaluations; every simulation is still played and the games are bit-identical
 (tests/test_eval_cache_gpu.py) -- so the same K plies are timed a second time with it on and reported in `eval_cache`
 (`value_with_eval_cache`); `--no-eval-cache` skips that region, `--eval-cache-in-value` measures `value` itself with it on.
+A third, supplementary region times the same K plies with `engine.tail_split = "halves"` (opt-in: every pass as two half batches
+side by side; `half_split.value_with_half_split`; `--no-half-split-region` skips it).  Neither extra region enters `value` or `roofline`.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = 3x3 320->320 implicit-GEMM conv (MFMA-bound); achieved = algorithmic FLOP /
@@ -203,6 +205,8 @@ def main():
                     help="engine.tail_split: evaluate a pass as a whole number of workgroup rounds + a concurrent tail on a second "
                          "instance over the same weights (bit-identical games; +0.4..0.5 %% measured, and the event-bracketed conv "
                          "times then include the tail's workgroups, so the default bench keeps one forward per pass)")
+    ap.add_argument("--no-half-split-region", action="store_true",
+                    help="skip the supplementary third timed region (the same plies with engine.tail_split = 'halves', reported in `half_split`)")
     ap.add_argument("--half-split", action="store_true",
                     help="engine.tail_split = 'halves': a pass as two half batches on two instances over the same weights, side by side "
                          "(bit-identical games; +1.3 %% measured: one half's attention blocks run beside the other half's convs).  The "
@@ -273,11 +277,13 @@ def main():
 
     substeps = -(-args.sims // args.leaves)          # passes of the hot path per searched ply (all games in step)
 
-    def measure(eval_cache: bool):
+    def measure(eval_cache: bool, split=None):
         """One engine, warm-up, then the timed region of exactly `--steps` searched plies per resident game."""
+        if split is None:
+            split = "halves" if args.half_split else args.tail_split
         kw = dict(concurrent_games=args.games, total_games=0, first_game_index=first_index, leaves_per_step=args.leaves,
                   virtual_loss_active=True, ssl_in_forward=args.ssl, record_games=False, eval_cache=eval_cache,
-                  tail_split=("halves" if args.half_split else args.tail_split))
+                  tail_split=split)
         if args.streams > 1:
             made = [be]
             e = eng.SelfplayPool(lambda: made.pop() if made else make_backend(),
@@ -337,6 +343,13 @@ def main():
     if not args.no_eval_cache and not primary_cache:
         dt2, tot2, _ = measure(True)
         second = {"dt": dt2, "evals": tot2[0], "plies": tot2[1], "gfin": tot2[2], "sims": tot2[9], "passes": tot2[10], "cached": tot2[11]}
+    # third region (supplementary, like the second): the same K plies with engine.tail_split = "halves" -- every pass as two half
+    # batches side by side (bit-identical games, tests/test_selfplay_gpu.py).  Kept OUT of `value` and of `roofline`: with two
+    # forwards in flight a launch shares the chip with the other half's kernels and its event-bracketed time describes no kernel
+    third = None
+    if not args.no_half_split_region and not args.half_split and not args.tail_split and args.streams == 1:
+        dt3, tot3, _ = measure(primary_cache, split="halves")
+        third = {"dt": dt3, "evals": tot3[0], "plies": tot3[1], "gfin": tot3[2], "rows_tail": tot3[12]}
 
     if rank == 0:
         ppg, basis_src = game_length_basis()
@@ -398,6 +411,17 @@ def main():
                          "drop-in worker's default): a leaf reached twice in a pass shares one batch row, positions evaluated "
                          "in earlier passes come from a per-game cache; every simulation is played and the games are "
                          "bit-identical (tests/test_eval_cache_gpu.py)"})),
+            "half_split": (None if third is None else
+                           {"in_value": False,
+                            "value_with_half_split": (third["gfin"] / third["dt"]) if third["gfin"] >= MIN_FINISHED * args.gpus
+                            else (third["plies"] / third["dt"]) / ppg,
+                            "plies_per_s": third["plies"] / third["dt"], "evals_per_s": third["evals"] / third["dt"],
+                            "ms_per_step": third["dt"] * 1e3 / max(1, args.steps),
+                            "share_of_evaluations_on_the_second_instance": third["rows_tail"] / max(1.0, third["evals"]),
+                            "note": "the same K plies timed once more with engine.tail_split = 'halves' (opt-in): every pass as two half "
+                                    "batches on two instances over the same weights, side by side, so that one half's attention blocks "
+                                    "run beside the other half's power-bound convs; same evaluation-cache setting as `value`; games "
+                                    "bit-identical.  Not in `value`, not in `roofline` (per-launch timings of the halves overlap)"}),
             "net_TFLOPs": evals * flops_eval / dt_max / 1e12,
             "passes_per_step": passes / max(1, args.steps), "ms_per_pass": dt_max * 1e3 / passes,
             # the timed region is the friendliest regime: all resident searches are in step, so every pass is a full batch and a
